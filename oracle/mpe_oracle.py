@@ -1,0 +1,474 @@
+"""CPU oracle for the particle-world step -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This file restates, in plain numpy float64, the arithmetic of the reference
+simulator's hot path so that the HIP kernels can be checked against it.  Only
+``tests/``, ``__graft_entry__.smoke()``, ``tools/gen_golden.py`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it; nothing under the product
+package does.  Parity of this oracle itself is pinned by the golden fixtures in
+``tests/golden/`` which ``tools/gen_golden.py`` captured by running the real
+reference code (see ``tests/test_oracle_golden.py``).
+
+Every array carries a leading batch axis ``B`` so the same code serves one env
+(``B == 1``, the CPU-baseline timing) and thousands (parity sweeps).  All
+elementwise operations are written in the *same order* as the reference's
+scalar code so that float64 results are bit-identical, not merely close:
+
+* ``pos``  float64 ``[B, E, 2]``   entity positions, agents first then landmarks
+                                   (reference ``World.entities``, multiagent/core.py:127-129)
+* ``vel``  float64 ``[B, A, 2]``   agent velocities (landmarks never move in scope)
+* ``comm`` float64 ``[B, A, dim_c]`` agent communication state ``state.c``
+* ``actions`` int ``[B, n_act]``   flattened reference ``action_n`` list: for each agent
+                                   its move int 0..4, followed by its comm int if the
+                                   agent is not silent (multiagent/environment.py:173-204)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+SCN_SPREAD = "simple_spread"
+SCN_TAG = "simple_tag"
+SCN_WORLD_COMM = "simple_world_comm"
+
+
+@dataclass
+class Spec:
+    """Static description of one scenario's world (what ``make_world`` builds)."""
+
+    scenario: str
+    A: int
+    L: int
+    dim_c: int
+    size: np.ndarray          # [E]
+    movable: np.ndarray       # [E] bool
+    collide: np.ndarray       # [E] bool
+    mass: np.ndarray          # [E]
+    sens: np.ndarray          # [A] accel if set else 5.0 (environment.py:192-195)
+    max_speed: np.ndarray     # [A] inf when the reference has None
+    silent: np.ndarray        # [A] bool
+    adversary: np.ndarray     # [A] bool
+    leader: np.ndarray        # [A] bool
+    # World.__init__ defaults, multiagent/core.py:117-124
+    dt: float = 0.1
+    damping: float = 0.25
+    contact_force: float = 1e2
+    contact_margin: float = 1e-3
+    # landmark roles for simple_world_comm (indices into the landmark list)
+    food: List[int] = field(default_factory=list)
+    forests: List[int] = field(default_factory=list)
+
+    @property
+    def E(self) -> int:
+        return self.A + self.L
+
+    @property
+    def n_act(self) -> int:
+        return int(self.A + np.count_nonzero(~self.silent))
+
+    @property
+    def obs_dims(self) -> List[int]:
+        A, L = self.A, self.L
+        if self.scenario == SCN_SPREAD:
+            return [4 + 2 * L + 2 * (A - 1)] * A
+        if self.scenario == SCN_TAG:
+            out = []
+            for i in range(A):
+                n_good_others = sum(1 for j in range(A) if j != i and not self.adversary[j])
+                out.append(4 + 2 * L + 2 * (A - 1) + 2 * n_good_others)
+            return out
+        if self.scenario == SCN_WORLD_COMM:
+            out = []
+            for i in range(A):
+                n_good_others = sum(1 for j in range(A) if j != i and not self.adversary[j])
+                d = 4 + 2 * L + 2 * (A - 1) + 2 * n_good_others + 2
+                if self.adversary[i]:
+                    d += self.dim_c
+                out.append(d)
+            return out
+        raise ValueError(self.scenario)
+
+
+def spec_spread(A: int = 3, L: int = 3) -> Spec:
+    """simple_spread.make_world, multiagent/scenarios/simple_spread.py:8-38.
+
+    The reference hard-codes 3 agents / 3 landmarks (:12-13); A and L are
+    parameters here for the scaled 64/64 configuration.
+    """
+    E = A + L
+    size = np.array([0.15] * A + [0.05] * L)                  # :29, core.py:50
+    movable = np.array([True] * A + [False] * L)              # core.py:83, :35
+    collide = np.array([True] * A + [False] * L)              # :27, :34
+    return Spec(SCN_SPREAD, A, L, 2, size, movable, collide, np.ones(E),
+                sens=np.full(A, 5.0), max_speed=np.full(A, np.inf),
+                silent=np.ones(A, bool), adversary=np.zeros(A, bool),
+                leader=np.zeros(A, bool))
+
+
+def spec_tag() -> Spec:
+    """simple_tag.make_world, multiagent/scenarios/simple_tag.py:7-36."""
+    n_adv, n_good, L = 3, 1, 2
+    A = n_adv + n_good
+    adv = np.array([True] * n_adv + [False] * n_good)
+    size = np.concatenate([np.where(adv, 0.075, 0.05), np.full(L, 0.2)])   # :22, :32
+    movable = np.array([True] * A + [False] * L)
+    collide = np.ones(A + L, bool)                                          # :19, :30
+    return Spec(SCN_TAG, A, L, 2, size, movable, collide, np.ones(A + L),
+                sens=np.where(adv, 3.0, 4.0),                               # :23
+                max_speed=np.where(adv, 1.0, 1.3),                          # :25
+                silent=np.ones(A, bool), adversary=adv, leader=np.zeros(A, bool))
+
+
+def spec_world_comm() -> Spec:
+    """simple_world_comm.make_world, multiagent/scenarios/simple_world_comm.py:7-57.
+
+    Landmark order is [obstacle, food0, food1, forest0, forest1] (:52-53).
+    """
+    n_adv, n_good = 4, 2
+    A = n_adv + n_good
+    L = 5
+    adv = np.array([True] * n_adv + [False] * n_good)
+    size = np.concatenate([np.where(adv, 0.075, 0.045), [0.2, 0.03, 0.03, 0.3, 0.3]])  # :26,:36,:43,:50
+    movable = np.array([True] * A + [False] * L)
+    collide = np.array([True] * A + [True, False, False, False, False])                # :22,:34,:41,:48
+    leader = np.array([i == 0 for i in range(A)])                                       # :23
+    silent = ~leader                                                                    # :24
+    return Spec(SCN_WORLD_COMM, A, L, 4, size, movable, collide, np.ones(A + L),
+                sens=np.where(adv, 3.0, 4.0), max_speed=np.where(adv, 1.0, 1.3),        # :27,:29
+                silent=silent, adversary=adv, leader=leader, food=[1, 2], forests=[3, 4])
+
+
+def make_spec(name: str, **kw) -> Spec:
+    if name == SCN_SPREAD:
+        return spec_spread(**kw)
+    if name == SCN_TAG:
+        return spec_tag()
+    if name == SCN_WORLD_COMM:
+        return spec_world_comm()
+    raise ValueError(name)
+
+
+# --------------------------------------------------------------------------
+# MultiAgentEnv._set_action, multiagent/environment.py:155-206 (discrete int input)
+# --------------------------------------------------------------------------
+def decode_actions(spec: Spec, actions: np.ndarray):
+    """int actions [B, n_act] -> (u [B, A, 2], c [B, A, dim_c])."""
+    actions = np.asarray(actions)
+    B = actions.shape[0]
+    u = np.zeros((B, spec.A, 2))
+    c = np.zeros((B, spec.A, spec.dim_c))
+    col = 0
+    for i in range(spec.A):
+        a = actions[:, col]
+        col += 1
+        # :178-181 ; ints outside 1..4 leave u at zero
+        u[:, i, 0] = np.where(a == 1, -1.0, np.where(a == 2, 1.0, 0.0))
+        u[:, i, 1] = np.where(a == 3, -1.0, np.where(a == 4, 1.0, 0.0))
+        u[:, i, :] *= spec.sens[i]                      # :192-195
+        if not spec.silent[i]:
+            k = actions[:, col]
+            col += 1
+            c[np.arange(B), i, k] = 1.0                 # :199-201
+    assert col == spec.n_act
+    return u, c
+
+
+# --------------------------------------------------------------------------
+# World.step, multiagent/core.py:142-158
+# --------------------------------------------------------------------------
+def _dist(d):
+    """sqrt(sum(square(delta))) for a length-2 delta, core.py:224."""
+    return np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1])
+
+
+def collision_force(spec: Spec, pa, pb, size_a, size_b):
+    """World.get_collision_force arithmetic, multiagent/core.py:222-230."""
+    delta = pa - pb
+    dist = _dist(delta)
+    dist_min = size_a + size_b
+    k = spec.contact_margin
+    with np.errstate(all="ignore"):
+        pen = np.logaddexp(0, -(dist - dist_min) / k) * k
+        force = spec.contact_force * delta / dist[..., None] * pen[..., None]
+    return force
+
+
+def world_step(spec: Spec, pos, vel, u, c):
+    """One World.step.  Returns new (pos, vel, comm); inputs are not modified."""
+    A, E = spec.A, spec.E
+    pos = np.array(pos, dtype=np.float64)
+    vel = np.array(vel, dtype=np.float64)
+    B = pos.shape[0]
+    # apply_action_force, core.py:161-167 (u_noise is None in scope -> + 0.0)
+    force: List[Optional[np.ndarray]] = [None] * E
+    for i in range(A):
+        if spec.movable[i]:
+            force[i] = u[:, i, :] + 0.0
+    # apply_environment_force, core.py:170-181
+    for a in range(E):
+        for b in range(a + 1, E):
+            if (not spec.collide[a]) or (not spec.collide[b]):
+                continue                                # core.py:216-217
+            if (not spec.movable[a]) and (not spec.movable[b]):
+                continue                                # core.py:218-219
+            f = collision_force(spec, pos[:, a, :], pos[:, b, :], spec.size[a], spec.size[b])
+            if spec.movable[a]:
+                if force[a] is None:
+                    force[a] = np.zeros((B, 2))
+                force[a] = (+f) + force[a]              # core.py:178
+            if spec.movable[b]:
+                if force[b] is None:
+                    force[b] = np.zeros((B, 2))
+                force[b] = (-f) + force[b]              # core.py:181
+    # integrate_state, core.py:193-204
+    for i in range(A):
+        if not spec.movable[i]:
+            continue
+        v = vel[:, i, :] * (1 - spec.damping)
+        if force[i] is not None:
+            v = v + (force[i] / spec.mass[i]) * spec.dt
+        if np.isfinite(spec.max_speed[i]):
+            with np.errstate(all="ignore"):
+                speed = np.sqrt(np.square(v[:, 0]) + np.square(v[:, 1]))
+                over = speed > spec.max_speed[i]
+                clamped = v / speed[:, None] * spec.max_speed[i]
+            v = np.where(over[:, None], clamped, v)
+        vel[:, i, :] = v
+        pos[:, i, :] = pos[:, i, :] + v * spec.dt
+    # update_agent_state, core.py:206-212
+    comm = np.zeros((B, A, spec.dim_c))
+    for i in range(A):
+        if not spec.silent[i]:
+            comm[:, i, :] = c[:, i, :] + 0.0
+    return pos, vel, comm
+
+
+# --------------------------------------------------------------------------
+# scenario callbacks
+# --------------------------------------------------------------------------
+def _is_collision(pos, i, j, size):
+    """Scenario.is_collision (simple_spread.py:77-81, simple_tag.py:69-73,
+    simple_world_comm.py:126-130): strict ``dist < size_i + size_j``."""
+    d = pos[:, i, :] - pos[:, j, :]
+    return _dist(d) < (size[i] + size[j])
+
+
+def _bound(x):
+    """bound(x) of simple_tag.py:103-108 / simple_world_comm.py:167-172."""
+    with np.errstate(all="ignore"):
+        big = np.minimum(np.exp(2 * x - 2), 10)
+    return np.where(x < 0.9, 0.0, np.where(x < 1.0, (x - 0.9) * 10, big))
+
+
+def observe(spec: Spec, pos, vel, comm) -> List[np.ndarray]:
+    """Per-agent observations.  Returns a list of A arrays ``[B, D_i]``."""
+    A, L = spec.A, spec.L
+    B = pos.shape[0]
+    out = []
+    if spec.scenario == SCN_SPREAD:
+        # simple_spread.py:110-130 ; result cast to float32 (:130)
+        for i in range(A):
+            parts = [vel[:, i, :], pos[:, i, :]]
+            parts += [pos[:, A + l, :] - pos[:, i, :] for l in range(L)]
+            parts += [pos[:, j, :] - pos[:, i, :] for j in range(A) if j != i]
+            out.append(np.concatenate(parts, axis=1).astype(np.float32))
+        return out
+    if spec.scenario == SCN_TAG:
+        # simple_tag.py:131-147 ; float64
+        for i in range(A):
+            parts = [vel[:, i, :], pos[:, i, :]]
+            parts += [pos[:, A + l, :] - pos[:, i, :] for l in range(L)]
+            parts += [pos[:, j, :] - pos[:, i, :] for j in range(A) if j != i]
+            parts += [vel[:, j, :] for j in range(A) if j != i and not spec.adversary[j]]
+            out.append(np.concatenate(parts, axis=1))
+        return out
+    if spec.scenario == SCN_WORLD_COMM:
+        # simple_world_comm.py:224-287
+        f1, f2 = A + spec.forests[0], A + spec.forests[1]
+        inf = np.stack([np.stack([_is_collision(pos, i, f, spec.size) for f in (f1, f2)], axis=1)
+                        for i in range(A)], axis=1)            # [B, A, 2] bool
+        for i in range(A):
+            parts = [vel[:, i, :], pos[:, i, :]]
+            parts += [pos[:, A + l, :] - pos[:, i, :] for l in range(L)]
+            inf1, inf2 = inf[:, i, 0], inf[:, i, 1]
+            in_forest = np.where(inf[:, i, :], 1.0, -1.0)      # :231-239
+            other_pos, other_vel = [], []
+            for j in range(A):
+                if j == i:
+                    continue
+                of1, of2 = inf[:, j, 0], inf[:, j, 1]
+                vis = (inf1 & of1) | (inf2 & of2) | (~inf1 & ~of1 & ~inf2 & ~of2)
+                if spec.leader[i]:
+                    vis = np.ones(B, bool)                      # :254
+                other_pos.append(np.where(vis[:, None], pos[:, j, :] - pos[:, i, :], 0.0))
+                if not spec.adversary[j]:
+                    other_vel.append(np.where(vis[:, None], vel[:, j, :], 0.0))
+            c0 = comm[:, 0, :]                                  # :279
+            if spec.adversary[i]:
+                parts = parts + other_pos + other_vel + [in_forest, c0]      # :281-285
+            else:
+                parts = parts + other_pos + [in_forest] + other_vel          # :287
+            out.append(np.concatenate(parts, axis=1))
+        return out
+    raise ValueError(spec.scenario)
+
+
+def visibility_masks(spec: Spec, pos):
+    """Integer masks of simple_world_comm.observation: (in_forest [B, A, 2] bool,
+    visible [B, A, A] bool with the diagonal False)."""
+    A = spec.A
+    B = pos.shape[0]
+    f1, f2 = A + spec.forests[0], A + spec.forests[1]
+    inf = np.stack([np.stack([_is_collision(pos, i, f, spec.size) for f in (f1, f2)], axis=1)
+                    for i in range(A)], axis=1)
+    vis = np.zeros((B, A, A), bool)
+    for i in range(A):
+        for j in range(A):
+            if i == j:
+                continue
+            v = (inf[:, i, 0] & inf[:, j, 0]) | (inf[:, i, 1] & inf[:, j, 1]) | \
+                (~inf[:, i, 0] & ~inf[:, j, 0] & ~inf[:, i, 1] & ~inf[:, j, 1])
+            vis[:, i, j] = True if spec.leader[i] else v
+    return inf, vis
+
+
+def reward(spec: Spec, pos) -> np.ndarray:
+    """Per-agent rewards ``[B, A]`` float64 (reference mixes Python ints and
+    numpy floats; the values are equal)."""
+    A, L = spec.A, spec.L
+    B = pos.shape[0]
+    rew = np.zeros((B, A))
+    if spec.scenario == SCN_SPREAD:
+        # simple_spread.py:83-108
+        for i in range(A):
+            r = np.zeros(B)
+            if i == 0:
+                for l in range(L):
+                    dists = np.stack([_dist(pos[:, a, :] - pos[:, A + l, :]) for a in range(A)], axis=0)
+                    r = r - dists.min(axis=0)
+            pen = np.zeros(B)
+            for a in range(A):
+                if a != i:
+                    pen = pen - _is_collision(pos, a, i, spec.size)
+            rew[:, i] = r + pen
+        return rew
+    good = [i for i in range(A) if not spec.adversary[i]]
+    advs = [i for i in range(A) if spec.adversary[i]]
+    if spec.scenario == SCN_TAG:
+        # simple_tag.py:84-129
+        n_pairs = np.zeros(B)
+        for g in good:
+            for a in advs:
+                n_pairs = n_pairs + 10 * _is_collision(pos, g, a, spec.size)
+        for i in range(A):
+            if spec.adversary[i]:
+                rew[:, i] = n_pairs
+            else:
+                r = np.zeros(B)
+                for a in advs:
+                    r = r - 10 * _is_collision(pos, a, i, spec.size)
+                for p in range(2):
+                    r = r - _bound(np.abs(pos[:, i, p]))
+                rew[:, i] = r
+        return rew
+    if spec.scenario == SCN_WORLD_COMM:
+        # simple_world_comm.py:142-198
+        hits = [(g, a, _is_collision(pos, g, a, spec.size)) for g in good for a in advs]
+        for i in range(A):
+            if spec.adversary[i]:
+                dmin = np.stack([_dist(pos[:, g, :] - pos[:, i, :]) for g in good], axis=0).min(axis=0)
+                r = 0 - 0.1 * dmin                                            # :192
+                for _, _, hit in hits:                                        # :194-197, one add per pair
+                    r = r + 5 * hit
+                rew[:, i] = r
+            else:
+                r = np.zeros(B)
+                for a in advs:
+                    r = r - 5 * _is_collision(pos, a, i, spec.size)           # :164-166
+                for p in range(2):
+                    r = r - 2 * _bound(np.abs(pos[:, i, p]))                  # :174-176
+                for f in spec.food:
+                    r = r + 2 * _is_collision(pos, i, A + f, spec.size)       # :178-180
+                fmin = np.stack([_dist(pos[:, A + f, :] - pos[:, i, :]) for f in spec.food],
+                                axis=0).min(axis=0)
+                r = r + 0.05 * fmin                                           # :181
+                rew[:, i] = r
+        return rew
+    raise ValueError(spec.scenario)
+
+
+def info(spec: Spec, pos):
+    """benchmark_data.  Returns dict of arrays.
+
+    simple_spread (simple_spread.py:58-74): ``rew`` [B, A] float, ``collisions``
+    [B, A] int, ``min_dists`` [B] float, ``occupied`` [B] int.
+    simple_tag / simple_world_comm (simple_tag.py:57-66,
+    simple_world_comm.py:115-123): ``collisions`` [B, A] int (0 for good agents).
+    """
+    A, L = spec.A, spec.L
+    B = pos.shape[0]
+    if spec.scenario == SCN_SPREAD:
+        min_dists = np.zeros(B)
+        r0 = np.zeros(B)
+        occupied = np.zeros(B, np.int64)
+        for l in range(L):
+            m = np.stack([_dist(pos[:, a, :] - pos[:, A + l, :]) for a in range(A)], axis=0).min(axis=0)
+            min_dists = min_dists + m
+            r0 = r0 - m
+            occupied = occupied + (m < 0.1)
+        coll = np.zeros((B, A), np.int64)
+        rew = np.zeros((B, A))
+        for i in range(A):
+            r = r0.copy()
+            for a in range(A):
+                if a != i:
+                    hit = _is_collision(pos, a, i, spec.size)
+                    r = r - hit
+                    coll[:, i] += hit
+            rew[:, i] = r
+        return {"rew": rew, "collisions": coll, "min_dists": min_dists, "occupied": occupied}
+    coll = np.zeros((B, A), np.int64)
+    good = [i for i in range(A) if not spec.adversary[i]]
+    for i in range(A):
+        if spec.adversary[i]:
+            for g in good:
+                coll[:, i] += _is_collision(pos, g, i, spec.size)
+    return {"collisions": coll}
+
+
+def env_step(spec: Spec, pos, vel, actions):
+    """MultiAgentEnv.step, multiagent/environment.py:83-115, for B envs.
+
+    Returns (pos, vel, comm, obs_list, rew [B, A], done [B] bool).
+    ``done`` is always False: no in-scope scenario supplies a done callback
+    (environment.py:143-146).
+    """
+    u, c = decode_actions(spec, actions)
+    pos, vel, comm = world_step(spec, pos, vel, u, c)
+    obs = observe(spec, pos, vel, comm)
+    rew = reward(spec, pos)
+    return pos, vel, comm, obs, rew, np.zeros(pos.shape[0], bool)
+
+
+def reset(spec: Spec, rng: np.random.RandomState, B: int = 1):
+    """reset_world distributions (simple_spread.py:48-54, simple_tag.py:47-54,
+    simple_world_comm.py:101-113): agents U(-1,1)^2; landmarks U(-1,1)^2 for
+    simple_spread and U(-0.9,0.9)^2 otherwise; zero velocity and comm.
+
+    The draw order of a single reference env is reproduced for B == 1 (the
+    simple_world_comm food/forest re-draws included); for B > 1 envs are drawn
+    one after another.
+    """
+    A, L = spec.A, spec.L
+    pos = np.zeros((B, spec.E, 2))
+    lim = 1.0 if spec.scenario == SCN_SPREAD else 0.9
+    for b in range(B):
+        for i in range(A):
+            pos[b, i] = rng.uniform(-1, +1, 2)
+        for l in range(L):
+            pos[b, A + l] = rng.uniform(-lim, +lim, 2)
+        if spec.scenario == SCN_WORLD_COMM:
+            for l in spec.food + spec.forests:
+                pos[b, A + l] = rng.uniform(-0.9, +0.9, 2)
+    return pos, np.zeros((B, A, 2)), np.zeros((B, A, spec.dim_c))

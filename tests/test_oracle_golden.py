@@ -1,0 +1,89 @@
+"""The numpy oracle against the fixtures captured from the reference.
+
+The fixtures hold what the reference's own MultiAgentEnv.step / World.step and
+scenario callbacks produced (tools/gen_golden.py); the oracle must reproduce
+float64 state, observations and rewards bit for bit and every integer field
+exactly.
+"""
+import numpy as np
+import pytest
+
+import mpe_oracle as orc
+from conftest import GOLDEN_CASES, load_golden
+
+
+@pytest.mark.parametrize("case", list(GOLDEN_CASES))
+def test_oracle_reproduces_reference_trajectory(case):
+    scn, kw = GOLDEN_CASES[case]
+    g = load_golden(case)
+    spec = orc.make_spec(scn, **kw)
+    assert spec.obs_dims == list(g["obs_dims"])
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    obs_steps = list(g["obs_steps"]) if "obs_steps" in g else None
+    for t in range(g["actions"].shape[0]):
+        pos, vel, comm, obs, rew, done = orc.env_step(spec, pos, vel, g["actions"][t])
+        assert np.array_equal(pos[:, :spec.A], g["pos"][t]), (case, t)
+        assert np.array_equal(vel, g["vel"][t]), (case, t)
+        assert np.array_equal(rew, g["rew"][t]), (case, t)
+        assert not done.any() and not g["done"][t].any()
+        if obs_steps is None:
+            assert np.array_equal(np.concatenate(obs, axis=1), g["obs"][t]), (case, t)
+        elif t in obs_steps:
+            assert np.array_equal(np.concatenate(obs, axis=1), g["obs"][obs_steps.index(t)])
+        inf = orc.info(spec, pos)
+        assert np.array_equal(inf["collisions"], g["collisions"][t])
+        if scn == "simple_spread":
+            assert np.array_equal(inf["rew"], g["info_rew"][t])
+            assert np.array_equal(inf["min_dists"], g["min_dists"][t])
+            assert np.array_equal(inf["occupied"], g["occupied"][t])
+        if scn == "simple_world_comm":
+            assert np.array_equal(comm[:, 0, :], g["comm"][t])
+            inforest, vis = orc.visibility_masks(spec, pos)
+            assert np.array_equal(inforest, g["in_forest"][t].astype(bool))
+            assert np.array_equal(vis, g["visible"][t].astype(bool))
+
+
+def test_known_answers():
+    k = load_golden("kat")
+    spec = orc.spec_spread()
+    # KAT1: seeded reset of the reference + actions (t+i) % 5
+    pos = k["kat1_pos0"][None].copy()
+    vel = np.zeros((1, 3, 2))
+    ret0 = 0.0
+    for t in range(25):
+        act = np.array([[(t + i) % 5 for i in range(3)]])
+        pos, vel, comm, obs, rew, done = orc.env_step(spec, pos, vel, act)
+        ret0 += rew[0, 0]
+    assert np.array_equal(pos[0, :3], k["kat1_pos"])
+    assert np.array_equal(vel[0], k["kat1_vel"])
+    assert np.array_equal(rew[0], k["kat1_rew"])
+    assert ret0 == float(k["kat1_return0"])
+    assert np.array_equal(np.concatenate(obs, axis=1)[0], k["kat1_obs"])
+    inf = orc.info(spec, pos)
+    assert [inf["rew"][0, 0], inf["collisions"][0, 0], inf["min_dists"][0], inf["occupied"][0]] == list(k["kat1_info0"])
+    # softplus penetration table through the contact force
+    for gap, fx in zip(k["pen_gaps"], k["pen_force_x"]):
+        f = orc.collision_force(spec, np.array([[0.0, 0.0]]), np.array([[0.3 + gap, 0.0]]), 0.15, 0.15)
+        assert np.array_equal(f[0, 0], fx, equal_nan=True)
+    # contact anchor: agents at (0,0),(0.2,0),(5,5) at rest, one no-op step
+    pos = np.zeros((1, 6, 2)); pos[0, 1] = (0.2, 0); pos[0, 2] = (5, 5); pos[0, 3:] = 9.0
+    p, v, *_ = orc.env_step(spec, pos, np.zeros((1, 3, 2)), np.zeros((1, 3), int))
+    assert np.allclose(p[0, :3], [[-0.1, 0], [0.3, 0], [5, 5]], atol=1e-15)
+    assert np.allclose(v[0], [[-1, 0], [1, 0], [0, 0]], atol=1e-15)
+
+
+def test_tag_speed_clamp_anchor():
+    g = load_golden("tag")
+    spec = orc.spec_tag()
+    speeds = np.hypot(g["vel"][9, 8, :, 0], g["vel"][9, 8, :, 1])
+    assert np.allclose(speeds, spec.max_speed, rtol=1e-15)
+
+
+def test_reset_distribution_shapes():
+    rng = np.random.RandomState(0)
+    for scn in ("simple_spread", "simple_tag", "simple_world_comm"):
+        spec = orc.make_spec(scn)
+        pos, vel, comm = orc.reset(spec, rng, B=3)
+        assert pos.shape == (3, spec.E, 2) and vel.shape == (3, spec.A, 2)
+        lim = 1.0 if scn == "simple_spread" else 0.9
+        assert np.abs(pos[:, spec.A:]).max() <= lim and np.abs(pos).max() <= 1.0

@@ -1,0 +1,488 @@
+#!/usr/bin/env python3
+"""Capture golden trajectories from the reference simulator.
+
+Runs ONLY in the build container, where the reference tree is mounted at
+/root/reference.  It imports the reference's own ``core.py``, ``environment.py``
+and scenario files by path, replays seeded initial states and integer action
+sequences through them for 25 steps, and writes small ``.npz`` fixtures to
+``tests/golden/``.  Nothing from the reference is copied: the fixtures hold
+inputs and the numbers the reference produced.
+
+``gym`` is not installed here, so an inert stand-in supplying only container
+classes (spaces, Env, registration, seeding) is registered before the import;
+it performs no arithmetic of the simulated path.
+
+Reference entry points used:
+  * simple_spread, simple_tag: ``MultiAgentEnv.step`` (multiagent/environment.py:83-115)
+    with ``benchmark_data`` as the info callback (make_env.py:40-41).
+    simple_tag's one-argument ``reset_world`` (simple_tag.py:39) is wrapped
+    because ``MultiAgentEnv.reset`` passes two (environment.py:119).
+  * simple_world_comm: the leader's Tuple action cannot pass ``_set_action``
+    (environment.py:159-171 only splits MultiDiscrete), so the leader's
+    ``action.u`` / ``action.c`` are written with the semantics of
+    environment.py:176-201 and ``World.step`` plus the scenario callbacks are
+    called directly; the other five agents go through ``_set_action``.
+  * simple_spread with 64 agents / 64 landmarks: the reference hard-codes 3/3
+    (simple_spread.py:12-13); the world is assembled here from the reference's
+    ``World/Agent/Landmark`` classes with the same property assignments
+    (simple_spread.py:24-35) and stepped with the reference's functions.
+
+Usage:  python tools/gen_golden.py [--check]
+  --check additionally replays every fixture through oracle/mpe_oracle.py and
+  reports the largest deviation (must be 0 for float64 state).
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+T_STEPS = 25
+
+
+# ----------------------------------------------------------------------------
+# inert gym stand-in + by-path loader
+# ----------------------------------------------------------------------------
+def _install_gym_stub():
+    gym = types.ModuleType("gym")
+
+    class Space:
+        pass
+
+    class Env:
+        pass
+
+    class Discrete(Space):
+        def __init__(self, n):
+            self.n = n
+
+    class Box(Space):
+        def __init__(self, low=None, high=None, shape=None, dtype=None):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    class Tuple(Space):
+        def __init__(self, spaces):
+            self.spaces = list(spaces)
+
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Discrete, spaces.Box, spaces.Tuple, spaces.Space = Discrete, Box, Tuple, Space
+    envs = types.ModuleType("gym.envs")
+    registration = types.ModuleType("gym.envs.registration")
+
+    class EnvSpec:
+        def __init__(self, *a, **k):
+            pass
+
+    registration.EnvSpec = EnvSpec
+    registration.register = lambda *a, **k: None
+    envs.registration = registration
+    utils = types.ModuleType("gym.utils")
+    seeding = types.ModuleType("gym.utils.seeding")
+    seeding.np_random = lambda seed=None: (np.random.RandomState(seed), seed)
+    utils.seeding = seeding
+    gym.Space, gym.Env, gym.spaces, gym.envs, gym.utils = Space, Env, spaces, envs, utils
+    for name, mod in [("gym", gym), ("gym.spaces", spaces), ("gym.envs", envs),
+                      ("gym.envs.registration", registration), ("gym.utils", utils),
+                      ("gym.utils.seeding", seeding)]:
+        sys.modules[name] = mod
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    _install_gym_stub()
+    pkg = types.ModuleType("multiagent")
+    pkg.__path__ = [os.path.join(REF, "multiagent")]   # skips __init__.py (imports real gym)
+    sys.modules["multiagent"] = pkg
+    ref = types.SimpleNamespace()
+    ref.core = _load("multiagent.core", os.path.join(REF, "multiagent", "core.py"))
+    _load("multiagent.scenario", os.path.join(REF, "multiagent", "scenario.py"))
+    _load("multiagent.multi_discrete", os.path.join(REF, "multiagent", "multi_discrete.py"))
+    ref.environment = _load("multiagent.environment", os.path.join(REF, "multiagent", "environment.py"))
+    ref.scenarios = {}
+    for n in ("simple_spread", "simple_tag", "simple_world_comm"):
+        ref.scenarios[n] = _load("ref_scn_" + n, os.path.join(REF, "multiagent", "scenarios", n + ".py"))
+    return ref
+
+
+# ----------------------------------------------------------------------------
+# driving the reference
+# ----------------------------------------------------------------------------
+def make_env(ref, name):
+    sc = ref.scenarios[name].Scenario()
+    world = sc.make_world()
+    if name == "simple_spread":
+        reset_cb = sc.reset_world
+    else:
+        reset_cb = lambda w, rng: sc.reset_world(w)     # one-argument reset_world
+    env = ref.environment.MultiAgentEnv(world, reset_cb, sc.reward, sc.observation, sc.benchmark_data)
+    return sc, world, env
+
+
+def make_spread_world(ref, A, L):
+    """simple_spread world with A agents and L landmarks built from the
+    reference classes (property assignments of simple_spread.py:24-35)."""
+    core = ref.core
+    sc = ref.scenarios["simple_spread"].Scenario()
+    world = core.World()
+    world.dim_c = 2
+    world.agents = [core.Agent() for _ in range(A)]
+    for i, ag in enumerate(world.agents):
+        ag.name = "agent %d" % i
+        ag.collide = True
+        ag.silent = True
+        ag.size = 0.15
+    world.landmarks = [core.Landmark() for _ in range(L)]
+    for i, lm in enumerate(world.landmarks):
+        lm.name = "landmark %d" % i
+        lm.collide = False
+        lm.movable = False
+    sc.reset_world(world, np.random.RandomState(0))
+    env = ref.environment.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data)
+    return sc, world, env
+
+
+def inject(world, pos, vel):
+    A = len(world.agents)
+    for i, ag in enumerate(world.agents):
+        ag.state.p_pos = np.array(pos[i], dtype=np.float64)
+        ag.state.p_vel = np.array(vel[i], dtype=np.float64)
+        ag.state.c = np.zeros(world.dim_c)
+    for l, lm in enumerate(world.landmarks):
+        lm.state.p_pos = np.array(pos[A + l], dtype=np.float64)
+        lm.state.p_vel = np.zeros(world.dim_p)
+
+
+def run_env_api(sc, world, env, name, pos0, vel0, actions, obs_steps=None):
+    """Replay through MultiAgentEnv.step.  actions [T, B, A] ints."""
+    T, B, A = actions.shape
+    E = pos0.shape[1]
+    rec = _alloc(name, T, B, A, world, env, obs_steps)
+    env.seed(0)
+    for b in range(B):
+        env.reset()
+        inject(world, pos0[b], vel0[b])
+        for t in range(T):
+            obs_n, rew_n, done, info_n = env.step([int(a) for a in actions[t, b]])
+            _record(rec, name, t, b, world, obs_n, rew_n, done, info_n["n"], obs_steps)
+    return rec
+
+
+def run_world_comm(sc, world, env, pos0, vel0, actions):
+    """actions [T, B, 7]: [leader move, leader comm, move of agents 1..5]."""
+    name = "simple_world_comm"
+    T, B, _ = actions.shape
+    A = len(world.agents)
+    rec = _alloc(name, T, B, A, world, env, None)
+    rec["in_forest"] = np.zeros((T, B, A, 2), np.uint8)
+    rec["visible"] = np.zeros((T, B, A, A), np.uint8)
+    for b in range(B):
+        sc.reset_world(world)
+        inject(world, pos0[b], vel0[b])
+        for t in range(T):
+            act = actions[t, b]
+            leader = world.agents[0]
+            # environment.py:176-181,192-195 (move) and :199-201 (comm one-hot)
+            u = np.zeros(world.dim_p)
+            m = int(act[0])
+            if m == 1: u[0] = -1.0
+            if m == 2: u[0] = +1.0
+            if m == 3: u[1] = -1.0
+            if m == 4: u[1] = +1.0
+            u *= leader.accel
+            leader.action.u = u
+            c = np.zeros(world.dim_c)
+            c[int(act[1])] = 1.0
+            leader.action.c = c
+            for i in range(1, A):
+                env._set_action(int(act[1 + i]), world.agents[i], env.action_space[i])
+            world.step()
+            obs_n = [sc.observation(ag, world) for ag in world.agents]
+            rew_n = [sc.reward(ag, world) for ag in world.agents]
+            inf_n = [sc.benchmark_data(ag, world) for ag in world.agents]
+            _record(rec, name, t, b, world, obs_n, rew_n, False, inf_n, None)
+            rec["comm"][t, b] = world.agents[0].state.c
+            # masks: forest membership through the reference's is_collision
+            inf = np.array([[sc.is_collision(ag, f) for f in world.forests] for ag in world.agents])
+            rec["in_forest"][t, b] = inf
+            for i in range(A):
+                for j in range(A):
+                    if i == j:
+                        continue
+                    v = (inf[i, 0] and inf[j, 0]) or (inf[i, 1] and inf[j, 1]) or \
+                        (not inf[i, 0] and not inf[j, 0] and not inf[i, 1] and not inf[j, 1]) or \
+                        world.agents[i].leader
+                    rec["visible"][t, b, i, j] = v
+    return rec
+
+
+def _alloc(name, T, B, A, world, env, obs_steps):
+    dims = [s.shape[0] for s in env.observation_space]
+    n_obs_t = T if obs_steps is None else len(obs_steps)
+    rec = {
+        "pos": np.zeros((T, B, A, 2)), "vel": np.zeros((T, B, A, 2)),
+        "obs": np.zeros((n_obs_t, B, sum(dims))), "obs_dims": np.array(dims, np.int64),
+        "rew": np.zeros((T, B, A)), "done": np.zeros((T, B), np.uint8),
+        "collisions": np.zeros((T, B, A), np.int64),
+    }
+    if name == "simple_spread":
+        rec.update({"info_rew": np.zeros((T, B, A)), "min_dists": np.zeros((T, B)),
+                    "occupied": np.zeros((T, B), np.int64)})
+    if name == "simple_world_comm":
+        rec["comm"] = np.zeros((T, B, world.dim_c))
+    return rec
+
+
+def _record(rec, name, t, b, world, obs_n, rew_n, done, inf_n, obs_steps):
+    for i, ag in enumerate(world.agents):
+        rec["pos"][t, b, i] = ag.state.p_pos
+        rec["vel"][t, b, i] = ag.state.p_vel
+    if obs_steps is None:
+        rec["obs"][t, b] = np.concatenate([np.asarray(o, np.float64) for o in obs_n])
+    elif t in obs_steps:
+        rec["obs"][obs_steps.index(t), b] = np.concatenate([np.asarray(o, np.float64) for o in obs_n])
+    rec["rew"][t, b] = [float(r) for r in rew_n]
+    rec["done"][t, b] = bool(done)
+    if name == "simple_spread":
+        for i, inf in enumerate(inf_n):
+            rec["info_rew"][t, b, i] = inf[0]
+            rec["collisions"][t, b, i] = inf[1]
+        rec["min_dists"][t, b] = inf_n[0][2]
+        rec["occupied"][t, b] = inf_n[0][3]
+    else:
+        rec["collisions"][t, b] = inf_n
+
+
+# ----------------------------------------------------------------------------
+# seeded initial states (inputs)
+# ----------------------------------------------------------------------------
+def init_spread3(rng, B=32):
+    A, L = 3, 3
+    pos = rng.uniform(-1, 1, (B, A + L, 2))
+    vel = np.zeros((B, A, 2))
+    # envs 16..23: two agents already overlapping / touching (dist_min = 0.3)
+    for k, b in enumerate(range(16, 24)):
+        d = [0.05, 0.15, 0.25, 0.29, 0.2999, 0.3001, 0.31, 0.35][k]
+        ang = rng.uniform(0, 2 * np.pi)
+        pos[b, 1] = pos[b, 0] + d * np.array([np.cos(ang), np.sin(ang)])
+    # envs 24..27: an agent sitting on / near a landmark (occupied threshold 0.1)
+    for k, b in enumerate(range(24, 28)):
+        d = [0.0, 0.05, 0.0999, 0.1001][k]
+        pos[b, A + 1] = pos[b, 2] + np.array([d, 0.0])
+    # env 28: contact anchor -- agents at (0,0), (0.2,0), (5,5)
+    pos[28, 0], pos[28, 1], pos[28, 2] = (0.0, 0.0), (0.2, 0.0), (5.0, 5.0)
+    # envs 29..31: all three agents clustered, with initial velocity
+    for b in range(29, 32):
+        c = rng.uniform(-0.5, 0.5, 2)
+        pos[b, :A] = c + rng.uniform(-0.2, 0.2, (A, 2))
+        vel[b] = rng.uniform(-1, 1, (A, 2))
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+    actions[:, 28, :] = 0
+    actions[:, 20, :] = 2                         # constant push
+    actions[:, 21, :] = np.array([2, 1, 4])       # agents 0 and 1 driven together
+    return pos, vel, actions
+
+
+def init_tag(rng, B=32):
+    A, L = 4, 2
+    pos = np.concatenate([rng.uniform(-1, 1, (B, A, 2)), rng.uniform(-0.9, 0.9, (B, L, 2))], axis=1)
+    vel = np.zeros((B, A, 2))
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+    # env 8: speed-clamp anchor, everybody pushes +x from rest, far apart
+    pos[8, :, :] = [(-3, -3), (-3, 3), (3, -3), (3, 3), (8, 8), (-8, 8)]
+    actions[:, 8, :] = 2
+    # envs 9..15: good agent (index 3) near / beyond the arena edge -> bound() branches
+    for k, b in enumerate(range(9, 16)):
+        x = [0.85, 0.8999, 0.95, 0.9999, 1.05, 1.6, 2.4][k]
+        pos[b, 3] = (x if k % 2 == 0 else -x, 0.3 * (-1) ** k * x)
+        actions[:, b, 3] = 2 if k % 2 == 0 else 1          # keeps heading outwards
+    # envs 16..21: adversary touching the good agent (dist_min = 0.125)
+    for k, b in enumerate(range(16, 22)):
+        d = [0.0, 0.06, 0.12, 0.1249, 0.1251, 0.2][k]
+        if d == 0.0:
+            d = 1e-3
+        ang = rng.uniform(0, 2 * np.pi)
+        pos[b, k % 3] = pos[b, 3] + d * np.array([np.cos(ang), np.sin(ang)])
+    # envs 22..27: agent pressed against an obstacle (dist_min = 0.275 / 0.25)
+    for k, b in enumerate(range(22, 28)):
+        ag = k % A
+        d = [0.1, 0.2, 0.27, 0.28, 0.24, 0.26][k]
+        ang = rng.uniform(0, 2 * np.pi)
+        pos[b, ag] = pos[b, A + (k % L)] + d * np.array([np.cos(ang), np.sin(ang)])
+    # envs 28..31: moving start
+    vel[28:32] = rng.uniform(-1.5, 1.5, (4, A, 2))
+    return pos, vel, actions
+
+
+def init_world_comm(rng, B=32):
+    A, L = 6, 5
+    pos = np.concatenate([rng.uniform(-1, 1, (B, A, 2)), rng.uniform(-0.9, 0.9, (B, L, 2))], axis=1)
+    vel = np.zeros((B, A, 2))
+    actions = np.zeros((T_STEPS, B, 7), np.int64)
+    actions[:, :, 0] = rng.randint(0, 5, (T_STEPS, B))
+    actions[:, :, 1] = (np.arange(T_STEPS)[:, None] + np.arange(B)[None, :]) % 4   # comm cycles 0..3
+    actions[:, :, 2:] = rng.randint(0, 5, (T_STEPS, B, 5))
+    f1, f2 = A + 3, A + 4
+    food1 = A + 1
+
+    def near(center, r):
+        ang = rng.uniform(0, 2 * np.pi)
+        return center + r * np.array([np.cos(ang), np.sin(ang)])
+
+    # envs 8..23: forests kept apart, agents placed to hit every visibility branch
+    for b in range(8, 24):
+        pos[b, f1] = (-0.5, -0.4)
+        pos[b, f2] = (0.5, 0.4)
+        k = b - 8
+        for i in range(A):
+            where = (k + i * (1 + k // 4)) % 4
+            if where == 0:
+                pos[b, i] = near(pos[b, f1], rng.uniform(0, 0.25))
+            elif where == 1:
+                pos[b, i] = near(pos[b, f2], rng.uniform(0, 0.25))
+            elif where == 2:
+                pos[b, i] = near(pos[b, f1], 0.3 + 0.075 + rng.uniform(-0.02, 0.02))   # at the rim
+            # where == 3: stays at its random position
+    # envs 24..25: overlapping forests, agents inside both
+    for b in (24, 25):
+        pos[b, f1] = (0.0, 0.0)
+        pos[b, f2] = (0.2, 0.0)
+        for i in range(A):
+            pos[b, i] = near(np.array([0.1, 0.0]), rng.uniform(0, 0.45))
+    # envs 26..28: good agent on food (dist_min = 0.075) and near the arena edge
+    for k, b in enumerate((26, 27, 28)):
+        pos[b, 4] = pos[b, food1] + np.array([[0.0, 0.01], [0.0749, 0.0], [0.0751, 0.0]][k])
+        pos[b, 5] = ([0.95, -0.2], [1.2, 0.97], [-0.93, -1.4])[k]
+        actions[:, b, 6] = 0
+    # envs 29..31: adversary touching a good agent (dist_min = 0.12) / the obstacle (0.275, 0.245)
+    for k, b in enumerate((29, 30, 31)):
+        pos[b, k] = near(pos[b, 4], [0.05, 0.1199, 0.1201][k])
+        pos[b, 3] = near(pos[b, A + 0], [0.2, 0.27, 0.28][k])
+        pos[b, 5] = near(pos[b, A + 0], [0.2, 0.24, 0.25][k])
+    vel[30:32] = rng.uniform(-1, 1, (2, A, 2))
+    return pos, vel, actions
+
+
+def init_spread64(rng, B=2):
+    A = L = 64
+    pos = rng.uniform(-1, 1, (B, A + L, 2))
+    vel = np.zeros((B, A, 2))
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+    return pos, vel, actions
+
+
+# ----------------------------------------------------------------------------
+def known_answers(ref):
+    """Anchors that do not use state injection."""
+    out = {}
+    # KAT1: simple_spread, env.seed(1); env.reset(); actions a[t][i] = (t+i) % 5
+    sc, world, env = make_env(ref, "simple_spread")
+    env.seed(1)
+    env.reset()
+    out["kat1_pos0"] = np.array([e.state.p_pos for e in world.entities])
+    ret0 = 0.0
+    for t in range(T_STEPS):
+        obs_n, rew_n, done, info = env.step([(t + i) % 5 for i in range(3)])
+        ret0 += rew_n[0]
+    out["kat1_pos"] = np.array([a.state.p_pos for a in world.agents])
+    out["kat1_vel"] = np.array([a.state.p_vel for a in world.agents])
+    out["kat1_rew"] = np.array([float(r) for r in rew_n])
+    out["kat1_return0"] = np.array(ret0)
+    out["kat1_info0"] = np.array([float(x) for x in info["n"][0]])
+    out["kat1_obs"] = np.concatenate([np.asarray(o, np.float64) for o in obs_n])
+    # comm_matrix metadata of simple_spread.make_world (simple_spread.py:15-22)
+    out["spread_comm_matrix"] = np.asarray(world.comm_matrix, np.float64)
+    # softplus penetration values through get_collision_force
+    core = ref.core
+    w = core.World()
+    a, b = core.Agent(), core.Agent()
+    a.size = b.size = 0.15
+    gaps = np.array([-0.3, -0.01, -1e-4, 0.0, 1e-4, 0.01, 0.05, 0.7, 0.75, 1.0])
+    fx = []
+    for g in gaps:
+        a.state.p_pos = np.array([0.0, 0.0])
+        b.state.p_pos = np.array([0.3 + g, 0.0])
+        fa, fb = w.get_collision_force(a, b)
+        fx.append(fa[0])
+    out["pen_gaps"] = gaps
+    out["pen_force_x"] = np.array(fx)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    ref = load_reference()
+    os.makedirs(OUT, exist_ok=True)
+    cases = {}
+
+    rng = np.random.RandomState(20240601)
+    pos0, vel0, actions = init_spread3(rng)
+    sc, world, env = make_env(ref, "simple_spread")
+    cases["spread3"] = ("simple_spread", dict(A=3, L=3), pos0, vel0, actions,
+                        run_env_api(sc, world, env, "simple_spread", pos0, vel0, actions))
+
+    rng = np.random.RandomState(20240602)
+    pos0, vel0, actions = init_tag(rng)
+    sc, world, env = make_env(ref, "simple_tag")
+    cases["tag"] = ("simple_tag", {}, pos0, vel0, actions,
+                    run_env_api(sc, world, env, "simple_tag", pos0, vel0, actions))
+
+    rng = np.random.RandomState(20240603)
+    pos0, vel0, actions = init_world_comm(rng)
+    sc, world, env = make_env(ref, "simple_world_comm")
+    cases["world_comm"] = ("simple_world_comm", {}, pos0, vel0, actions,
+                           run_world_comm(sc, world, env, pos0, vel0, actions))
+
+    rng = np.random.RandomState(20240604)
+    pos0, vel0, actions = init_spread64(rng)
+    sc, world, env = make_spread_world(ref, 64, 64)
+    obs_steps = [0, T_STEPS - 1]
+    rec = run_env_api(sc, world, env, "simple_spread", pos0, vel0, actions, obs_steps=obs_steps)
+    rec["obs_steps"] = np.array(obs_steps)
+    cases["spread64"] = ("simple_spread", dict(A=64, L=64), pos0, vel0, actions, rec)
+
+    for key, (scn, kw, pos0, vel0, actions, rec) in cases.items():
+        path = os.path.join(OUT, key + ".npz")
+        np.savez_compressed(path, scenario=np.array(scn), pos0=pos0, vel0=vel0,
+                            actions=actions.astype(np.int32), **rec)
+        print("wrote", path, os.path.getsize(path), "bytes")
+    kat = known_answers(ref)
+    np.savez_compressed(os.path.join(OUT, "kat.npz"), **kat)
+    print("wrote kat.npz")
+
+    if args.check:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mpe_oracle as orc
+        for key, (scn, kw, pos0, vel0, actions, rec) in cases.items():
+            spec = orc.make_spec(scn, **kw)
+            pos, vel = pos0.copy(), vel0.copy()
+            worst = {}
+            for t in range(actions.shape[0]):
+                pos, vel, comm, obs, rew, done = orc.env_step(spec, pos, vel, actions[t])
+                dev = {
+                    "pos": np.abs(pos[:, :spec.A] - rec["pos"][t]).max(),
+                    "vel": np.abs(vel - rec["vel"][t]).max(),
+                    "rew": np.abs(rew - rec["rew"][t]).max(),
+                }
+                if "obs_steps" not in rec:
+                    dev["obs"] = np.abs(np.concatenate(obs, axis=1) - rec["obs"][t]).max()
+                for k, v in dev.items():
+                    worst[k] = max(worst.get(k, 0.0), float(v))
+            print(key, "oracle-vs-reference max |delta|:", worst)
+
+
+if __name__ == "__main__":
+    main()
