@@ -1,0 +1,158 @@
+/*
+ * mpe_hip -- C ABI of the MI355X (gfx950) batched particle-world simulator.
+ *
+ * The reference simulator (hepengli/multiagent-particle-envs) is pure Python and has no FFI;
+ * each entry point below names the Python function(s) it replaces for a batch of B independent
+ * worlds.  A Python binding loads this library with ctypes and passes raw device pointers
+ * (tensor.data_ptr()) and the caller's HIP stream.
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a negative MPE_ERR_* code on failure; nothing is
+ *     thrown across the boundary.  mpe_last_error() returns a description of the last failure
+ *     on a handle (or of the last failed mpe_create when called with NULL).
+ *   - The caller allocates and owns every buffer.  All data pointers are DEVICE pointers on the
+ *     handle's device.  The library only holds the immutable world description and a small
+ *     per-entity table in device memory.
+ *   - Kernels are enqueued on the caller's stream and the call returns without synchronising.
+ *   - A handle is not thread-safe; distinct handles are independent.  There is no global state.
+ *
+ * Memory layout (T = float for MPE_F32, double for MPE_F64; B = n_envs; E = A + L entities,
+ * agents first, then landmarks -- the order of World.entities, multiagent/core.py:127-129)
+ *   pos      T[2E][B]        row 2e+d holds coordinate d of entity e for every env (env-minor)
+ *   vel      T[2A][B]        same for agent velocities (landmarks never move)
+ *   comm     T[S*dim_c][B]   state.c of the S non-silent agents, in agent order (may be NULL if S == 0)
+ *   actions  int32[B][n_act] per env, the reference's action_n list flattened: for each agent its
+ *                            move int 0..4, followed by its comm int 0..dim_c-1 if it is not silent
+ *   obs      T[B][obs_total] per env, the agents' observation vectors concatenated in agent order;
+ *                            agent i owns columns [obs_offset[i], obs_offset[i] + obs_dim[i])
+ *   rew      T[B][A]
+ *   done     uint8[B]        always 0: no in-scope scenario has a done callback (environment.py:143-146)
+ *   info_i   int32[B][n_info_i]   optional (NULL to skip), see mpe_layout
+ *   info_f   T[B][n_info_f]       optional (NULL to skip)
+ */
+#ifndef MPE_HIP_H
+#define MPE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPE_OK 0
+#define MPE_ERR_INVALID (-1)     /* bad argument / spec does not match the scenario's structure */
+#define MPE_ERR_UNSUPPORTED (-2) /* valid request the library has no kernel for */
+#define MPE_ERR_HIP (-3)         /* a HIP runtime call failed */
+
+#define MPE_F32 0
+#define MPE_F64 1
+
+/* scenario ids */
+#define MPE_SCN_NONE 0       /* physics only: World.step without scenario callbacks */
+#define MPE_SCN_SPREAD 1     /* multiagent/scenarios/simple_spread.py */
+#define MPE_SCN_TAG 2        /* multiagent/scenarios/simple_tag.py */
+#define MPE_SCN_WORLD_COMM 3 /* multiagent/scenarios/simple_world_comm.py */
+
+#define MPE_MAX_AGENTS 64
+#define MPE_MAX_LANDMARKS 64
+
+typedef void* mpe_stream_t; /* hipStream_t */
+
+/*
+ * What Scenario.make_world() builds: World scalars (multiagent/core.py:117-124) and the static
+ * properties of every entity (core.py:45-101).  Arrays are HOST pointers, copied by mpe_create.
+ */
+typedef struct MpeSpec {
+    int32_t scenario;    /* MPE_SCN_* */
+    int32_t n_agents;    /* A */
+    int32_t n_landmarks; /* L */
+    int32_t dim_c;       /* World.dim_c */
+    double dt;             /* World.dt             (0.1)  */
+    double damping;        /* World.damping        (0.25) */
+    double contact_force;  /* World.contact_force  (1e2)  */
+    double contact_margin; /* World.contact_margin (1e-3) */
+    const double* size;       /* [E] Entity.size */
+    const double* mass;       /* [E] Entity.mass */
+    const uint8_t* movable;   /* [E] Entity.movable */
+    const uint8_t* collide;   /* [E] Entity.collide */
+    const double* sensitivity; /* [A] Agent.accel, or 5.0 when accel is None (environment.py:192-195) */
+    const double* max_speed;  /* [A] Entity.max_speed, or +inf when None (core.py:199) */
+    const uint8_t* silent;    /* [A] Agent.silent */
+    const uint8_t* adversary; /* [A] agent.adversary (simple_tag.py:21); zeros otherwise */
+    const uint8_t* leader;    /* [A] agent.leader (simple_world_comm.py:23); zeros otherwise */
+} MpeSpec;
+
+/* Derived sizes of the caller-allocated buffers. */
+typedef struct MpeLayout {
+    int64_t n_envs;
+    int32_t n_agents, n_landmarks, dim_c;
+    int32_t n_speakers;  /* S: agents with silent == 0 */
+    int32_t n_act;       /* A + S */
+    int32_t obs_total;   /* sum of obs_dim */
+    int32_t n_info_i;    /* simple_spread: A collision counts + occupied_landmarks;
+                            simple_tag: A collision counts;
+                            simple_world_comm: A collision counts + in_forest bits (bit 2i+f)
+                            + visibility bits (bit A*i+j) */
+    int32_t n_info_f;    /* simple_spread: min_dists + A benchmark rewards; otherwise 0 */
+    int32_t obs_dim[MPE_MAX_AGENTS];
+    int32_t obs_offset[MPE_MAX_AGENTS];
+} MpeLayout;
+
+typedef struct MpeHandle MpeHandle;
+
+/* Scenario.make_world() + MultiAgentEnv.__init__ (make_env.py:36-43, environment.py:15-69)
+ * for n_envs worlds of one scenario on HIP device `device`. */
+int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHandle** out);
+int mpe_destroy(MpeHandle* h);
+int mpe_layout(const MpeHandle* h, MpeLayout* out);
+const char* mpe_last_error(const MpeHandle* h);
+
+/*
+ * MultiAgentEnv.step (environment.py:83-115) for every env of the batch:
+ *   _set_action (environment.py:155-206, discrete int input) ->
+ *   World.step (core.py:142-158: apply_action_force :161-167, apply_environment_force :170-181 with
+ *   get_collision_force :215-233, integrate_state :193-204, update_agent_state :206-212) ->
+ *   the scenario's observation / reward / benchmark_data callbacks.
+ * pos, vel and comm are updated in place.
+ */
+int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
+             void* rew, uint8_t* done, int32_t* info_i, void* info_f, mpe_stream_t stream);
+
+/*
+ * n_steps consecutive MultiAgentEnv.step calls in one launch, for pre-computed actions (the
+ * "random actions" benchmark loop and scripted policies).  Buffers gain a leading step axis:
+ * actions int32[n_steps][B][n_act], obs T[n_steps][B][obs_total], rew T[n_steps][B][A],
+ * done uint8[n_steps][B], info_* likewise.  pos/vel/comm hold the state before the first step on
+ * entry and after the last on return.
+ */
+int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
+                void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps,
+                mpe_stream_t stream);
+
+/* The per-agent observation callbacks on the current state (what MultiAgentEnv.reset returns,
+ * environment.py:122-127) without stepping. */
+int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs,
+                mpe_stream_t stream);
+
+/*
+ * Scenario.reset_world (simple_spread.py:40-56, simple_tag.py:39-54, simple_world_comm.py:88-113)
+ * for every env whose mask byte is non-zero (all envs when mask is NULL): agent positions
+ * U(-1,1)^2, landmark positions U(-1,1)^2 (simple_spread) or U(-0.9,0.9)^2, zero velocity and comm.
+ * Draws come from a counter-based generator keyed by (seed, env index, episode); they follow the
+ * reference's distributions, not numpy's Mersenne-Twister stream.
+ */
+int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask, void* pos,
+              void* vel, void* comm, mpe_stream_t stream);
+
+/*
+ * World.step alone (core.py:142-158) for scenarios whose callbacks stay in Python: forces u
+ * T[2A][B] (already scaled, i.e. agent.action.u) and comm actions c T[S*dim_c][B] are given
+ * directly; pos, vel, comm are updated in place.
+ */
+int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* vel, void* comm,
+                   mpe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPE_HIP_H */

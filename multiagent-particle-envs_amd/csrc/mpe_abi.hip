@@ -1,0 +1,227 @@
+// extern "C" boundary of libmpe_hip.so: handle life cycle, argument validation and dispatch.
+// Declarations and the reference functions each entry point replaces: include/mpe_hip.h.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "mpe_launch.hpp"
+
+using namespace mpe;
+
+struct MpeHandle {
+    HostSpec spec;
+    MpeLayout layout;
+    int dtype;
+    int device;
+    char err[512];
+};
+
+static thread_local char g_create_err[512] = "";
+
+static int fail(MpeHandle* h, int code, const char* fmt, ...) {
+    char* dst = h ? h->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(MpeHandle* h, hipError_t e, const char* what) {
+    return fail(h, MPE_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+// The specialised kernels fix a scenario's structure at compile time; refuse a spec that
+// disagrees with it instead of silently simulating something else.
+static const char* check_structure(const HostSpec& s) {
+    const int A = s.A, L = s.L;
+    for (int i = 0; i < A; ++i)
+        if (!s.movable[i]) return "agents must be movable";
+    for (int l = 0; l < L; ++l)
+        if (s.movable[A + l]) return "landmarks must not be movable";
+    switch (s.scenario) {
+        case MPE_SCN_NONE:
+            return nullptr;
+        case MPE_SCN_SPREAD:
+            for (int i = 0; i < A; ++i)
+                if (!s.collide[i] || !s.silent[i]) return "simple_spread agents collide and are silent";
+            for (int l = 0; l < L; ++l)
+                if (s.collide[A + l]) return "simple_spread landmarks do not collide";
+            return nullptr;
+        case MPE_SCN_TAG:
+            if (A != 4 || L != 2) return "simple_tag has 4 agents and 2 landmarks";
+            for (int e = 0; e < A + L; ++e)
+                if (!s.collide[e]) return "simple_tag entities all collide";
+            for (int i = 0; i < A; ++i)
+                if (!s.silent[i] || s.adversary[i] != (i < 3)) return "simple_tag agents are silent, the first 3 are adversaries";
+            return nullptr;
+        case MPE_SCN_WORLD_COMM:
+            if (A != 6 || L != 5 || s.dim_c != 4) return "simple_world_comm has 6 agents, 5 landmarks, dim_c 4";
+            for (int i = 0; i < A; ++i)
+                if (!s.collide[i] || s.adversary[i] != (i < 4) || s.leader[i] != (i == 0) || s.silent[i] != (i != 0))
+                    return "simple_world_comm: 4 adversaries then 2 good agents, agent 0 leads and speaks";
+            for (int l = 0; l < L; ++l)
+                if (s.collide[A + l] != (l == 0)) return "simple_world_comm: only the first landmark collides";
+            return nullptr;
+    }
+    return "unknown scenario id";
+}
+
+static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
+    memset(lo, 0, sizeof(*lo));
+    const int A = s.A, L = s.L;
+    lo->n_envs = n_envs;
+    lo->n_agents = A;
+    lo->n_landmarks = L;
+    lo->dim_c = s.dim_c;
+    int speakers = 0, n_good = 0;
+    for (int i = 0; i < A; ++i) {
+        speakers += s.silent[i] ? 0 : 1;
+        n_good += s.adversary[i] ? 0 : 1;
+    }
+    lo->n_speakers = speakers;
+    lo->n_act = A + speakers;
+    int off = 0;
+    for (int i = 0; i < A; ++i) {
+        int d = 0;
+        const int good_others = n_good - (s.adversary[i] ? 0 : 1);
+        switch (s.scenario) {
+            case MPE_SCN_SPREAD: d = 4 + 2 * L + 2 * (A - 1); break;
+            case MPE_SCN_TAG: d = 4 + 2 * L + 2 * (A - 1) + 2 * good_others; break;
+            case MPE_SCN_WORLD_COMM: d = 4 + 2 * L + 2 * (A - 1) + 2 * good_others + 2 + (s.adversary[i] ? s.dim_c : 0); break;
+            default: d = 0;
+        }
+        lo->obs_dim[i] = d;
+        lo->obs_offset[i] = off;
+        off += d;
+    }
+    lo->obs_total = off;
+    switch (s.scenario) {
+        case MPE_SCN_SPREAD: lo->n_info_i = A + 1; lo->n_info_f = A + 1; break;
+        case MPE_SCN_TAG: lo->n_info_i = A; break;
+        case MPE_SCN_WORLD_COMM: lo->n_info_i = A + 2; break;
+        default: break;
+    }
+}
+
+extern "C" {
+
+int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHandle** out) {
+    if (!out) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: out is NULL");
+    *out = nullptr;
+    if (!spec) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: spec is NULL");
+    if (n_envs <= 0) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: n_envs must be positive (got %lld)", (long long)n_envs);
+    if (dtype != MPE_F32 && dtype != MPE_F64) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: dtype must be MPE_F32 or MPE_F64");
+    const int A = spec->n_agents, L = spec->n_landmarks;
+    if (A < 1 || A > MPE_MAX_AGENTS || L < 0 || L > MPE_MAX_LANDMARKS)
+        return fail(nullptr, MPE_ERR_INVALID, "mpe_create: need 1..%d agents and 0..%d landmarks (got %d, %d)", MPE_MAX_AGENTS, MPE_MAX_LANDMARKS, A, L);
+    if (!spec->size || !spec->mass || !spec->movable || !spec->collide || !spec->sensitivity || !spec->max_speed || !spec->silent)
+        return fail(nullptr, MPE_ERR_INVALID, "mpe_create: a required per-entity array is NULL");
+    if (spec->dim_c < 0 || spec->dim_c > 16) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: dim_c out of range");
+    if (!(spec->contact_margin > 0) || !(spec->dt > 0)) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: dt and contact_margin must be positive");
+
+    MpeHandle* h = new (std::nothrow) MpeHandle();
+    if (!h) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: out of host memory");
+    memset(h, 0, sizeof(*h));
+    HostSpec& s = h->spec;
+    s.scenario = spec->scenario; s.A = A; s.L = L; s.dim_c = spec->dim_c;
+    s.dt = spec->dt; s.damping = spec->damping; s.contact_force = spec->contact_force; s.contact_margin = spec->contact_margin;
+    for (int e = 0; e < A + L; ++e) {
+        s.size[e] = spec->size[e]; s.mass[e] = spec->mass[e];
+        s.movable[e] = spec->movable[e] ? 1 : 0; s.collide[e] = spec->collide[e] ? 1 : 0;
+        if (!(s.mass[e] > 0)) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: entity %d has non-positive mass", e); }
+    }
+    for (int i = 0; i < A; ++i) {
+        s.sens[i] = spec->sensitivity[i]; s.max_speed[i] = spec->max_speed[i];
+        s.silent[i] = spec->silent[i] ? 1 : 0;
+        s.adversary[i] = (spec->adversary && spec->adversary[i]) ? 1 : 0;
+        s.leader[i] = (spec->leader && spec->leader[i]) ? 1 : 0;
+        if (isnan(s.max_speed[i])) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: max_speed[%d] is NaN (use +inf for no limit)", i); }
+    }
+    if (const char* why = check_structure(s)) {
+        delete h;
+        return fail(nullptr, MPE_ERR_INVALID, "mpe_create: spec does not match scenario %d: %s", spec->scenario, why);
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess) { delete h; return hip_fail(nullptr, e, "hipGetDeviceCount"); }
+    if (device < 0 || device >= n_dev) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: device %d out of range (%d visible)", device, n_dev); }
+    h->dtype = dtype;
+    h->device = device;
+    fill_layout(s, n_envs, &h->layout);
+    if (s.scenario != MPE_SCN_NONE && !small_supported(s)) {
+        delete h;
+        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: no kernel for scenario %d with %d agents / %d landmarks", s.scenario, A, L);
+    }
+    *out = h;
+    return MPE_OK;
+}
+
+int mpe_destroy(MpeHandle* h) {
+    delete h;
+    return MPE_OK;
+}
+
+int mpe_layout(const MpeHandle* h, MpeLayout* out) {
+    if (!h || !out) return MPE_ERR_INVALID;
+    *out = h->layout;
+    return MPE_OK;
+}
+
+const char* mpe_last_error(const MpeHandle* h) { return h ? h->err : g_create_err; }
+
+static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, const char* who) {
+    if (!h) return MPE_ERR_INVALID;
+    if (h->spec.scenario == MPE_SCN_NONE) return fail(h, MPE_ERR_INVALID, "%s: handle was created with MPE_SCN_NONE; use mpe_world_step", who);
+    if (!a.pos || !a.vel || !a.obs) return fail(h, MPE_ERR_INVALID, "%s: pos, vel and obs must not be NULL", who);
+    if (h->layout.n_speakers > 0 && !a.comm) return fail(h, MPE_ERR_INVALID, "%s: comm must not be NULL for a scenario with speaking agents", who);
+    if (mode != 2 && (!a.actions || !a.rew || !a.done)) return fail(h, MPE_ERR_INVALID, "%s: actions, rew and done must not be NULL", who);
+    if (mode == 1 && a.n_steps < 1) return fail(h, MPE_ERR_INVALID, "%s: n_steps must be >= 1", who);
+    if (a.info_f && !a.info_i) return fail(h, MPE_ERR_INVALID, "%s: info_f requires info_i", who);
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
+    e = launch_small(h->spec, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(h, e, who);
+    return MPE_OK;
+}
+
+int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs, void* rew,
+             uint8_t* done, int32_t* info_i, void* info_f, mpe_stream_t stream) {
+    const StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, 1};
+    return run(h, 0, a, stream, "mpe_step");
+}
+
+int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs, void* rew,
+                uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps, mpe_stream_t stream) {
+    const StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_steps};
+    return run(h, 1, a, stream, "mpe_rollout");
+}
+
+int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs, mpe_stream_t stream) {
+    const StepArgs a{nullptr, (void*)pos, (void*)vel, (void*)comm, obs, nullptr, nullptr, nullptr, nullptr, 1};
+    return run(h, 2, a, stream, "mpe_observe");
+}
+
+int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask, void* pos, void* vel, void* comm,
+              mpe_stream_t stream) {
+    if (!h) return MPE_ERR_INVALID;
+    if (!pos || !vel) return fail(h, MPE_ERR_INVALID, "mpe_reset: pos and vel must not be NULL");
+    const int comm_rows = h->layout.n_speakers * h->spec.dim_c;
+    if (comm_rows > 0 && !comm) return fail(h, MPE_ERR_INVALID, "mpe_reset: comm must not be NULL for a scenario with speaking agents");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
+    e = launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, seed, episode, mask, pos, vel, comm, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(h, e, "mpe_reset");
+    return MPE_OK;
+}
+
+int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* vel, void* comm, mpe_stream_t stream) {
+    (void)u; (void)c; (void)pos; (void)vel; (void)comm; (void)stream;
+    if (!h) return MPE_ERR_INVALID;
+    return fail(h, MPE_ERR_UNSUPPORTED, "mpe_world_step: not built yet");
+}
+
+}  // extern "C"

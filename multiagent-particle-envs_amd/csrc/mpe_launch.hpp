@@ -1,0 +1,47 @@
+// Host-side description of a world and the launcher entry points shared by the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mpe_hip.h"
+
+namespace mpe {
+
+constexpr int MAX_E = MPE_MAX_AGENTS + MPE_MAX_LANDMARKS;
+
+// Validated copy of MpeSpec (host memory).
+struct HostSpec {
+    int scenario, A, L, dim_c;
+    double dt, damping, contact_force, contact_margin;
+    double size[MAX_E], mass[MAX_E];
+    uint8_t movable[MAX_E], collide[MAX_E];
+    double sens[MPE_MAX_AGENTS], max_speed[MPE_MAX_AGENTS];
+    uint8_t silent[MPE_MAX_AGENTS], adversary[MPE_MAX_AGENTS], leader[MPE_MAX_AGENTS];
+    int E() const { return A + L; }
+    bool any_speed_limit() const {
+        for (int i = 0; i < A; ++i) if (isfinite(max_speed[i])) return true;
+        return false;
+    }
+};
+
+struct StepArgs {
+    const int32_t* actions;
+    void *pos, *vel, *comm, *obs, *rew;
+    uint8_t* done;
+    int32_t* info_i;
+    void* info_f;
+    int n_steps;
+};
+
+// small in-register scenarios (mpe_small.hip); mode: 0 step, 1 rollout, 2 observe
+bool small_supported(const HostSpec& s);
+hipError_t launch_small(const HostSpec& s, long long n_envs, int dtype, int mode, const StepArgs& a, hipStream_t st);
+
+}  // namespace mpe
+
+namespace mpe {
+// on-device reset_world (mpe_reset.hip)
+hipError_t launch_reset(const HostSpec& s, long long n_envs, int dtype, int comm_rows, unsigned long long seed,
+                        unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, hipStream_t st);
+}  // namespace mpe

@@ -1,0 +1,133 @@
+// Scalar building blocks of the particle-world step, shared by every kernel.
+//
+// Everything here is written so that the float64 instantiation performs the same IEEE operations
+// in the same order as the reference's numpy scalar code (compile with -ffp-contract=off so no
+// multiply-add is fused); the float32 instantiation is the throughput variant.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpe {
+
+template <typename T> struct V2 { T x, y; };
+
+template <typename T> __device__ __forceinline__ T t_sqrt(T v);
+template <> __device__ __forceinline__ float t_sqrt<float>(float v) { return sqrtf(v); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double v) { return sqrt(v); }
+
+template <typename T> __device__ __forceinline__ T t_exp(T v);
+template <> __device__ __forceinline__ float t_exp<float>(float v) { return expf(v); }
+template <> __device__ __forceinline__ double t_exp<double>(double v) { return exp(v); }
+
+template <typename T> __device__ __forceinline__ T t_log1p(T v);
+template <> __device__ __forceinline__ float t_log1p<float>(float v) { return log1pf(v); }
+template <> __device__ __forceinline__ double t_log1p<double>(double v) { return log1p(v); }
+
+template <typename T> __device__ __forceinline__ T t_abs(T v);
+template <> __device__ __forceinline__ float t_abs<float>(float v) { return fabsf(v); }
+template <> __device__ __forceinline__ double t_abs<double>(double v) { return fabs(v); }
+
+// sqrt(sum(square(delta))) of a 2-vector: multiagent/core.py:224 and every is_collision.
+template <typename T> __device__ __forceinline__ T norm2(T dx, T dy) { return t_sqrt<T>(dx * dx + dy * dy); }
+
+// numpy.logaddexp(0, y) (npy_logaddexp): y == 0 -> ln 2; y < 0 -> log1p(exp(y));
+// y > 0 -> y + log1p(exp(-y)); NaN propagates.  multiagent/core.py:229.
+template <typename T> __device__ __forceinline__ T logaddexp0(T y) {
+    const T ay = t_abs<T>(y);
+    const T pos = y > T(0) ? y : T(0);
+    T r = pos + t_log1p<T>(t_exp<T>(-ay));
+    if (y == T(0)) r = T(0.693147180559945309417232121458176568);
+    return r;
+}
+
+// Force on entity a of the pair (a, b); entity b receives the negation.
+// World.get_collision_force, multiagent/core.py:222-230:
+//   delta = pa - pb; dist = |delta|; pen = logaddexp(0, -(dist - dist_min)/k) * k;
+//   force = contact_force * delta / dist * pen          (left to right)
+// dist == 0 yields NaN exactly as the reference does.
+template <typename T>
+__device__ __forceinline__ V2<T> contact_force(V2<T> pa, V2<T> pb, T dist_min, T cf, T k) {
+    const T dx = pa.x - pb.x, dy = pa.y - pb.y;
+    const T dist = norm2<T>(dx, dy);
+    const T pen = logaddexp0<T>(-(dist - dist_min) / k) * k;
+    V2<T> f;
+    f.x = cf * dx / dist * pen;
+    f.y = cf * dy / dist * pen;
+    return f;
+}
+
+// Scenario.is_collision: strict dist < size_1 + size_2 (simple_spread.py:77-81,
+// simple_tag.py:69-73, simple_world_comm.py:126-130).
+template <typename T> __device__ __forceinline__ bool touching(V2<T> p1, V2<T> p2, T dist_min) {
+    return norm2<T>(p1.x - p2.x, p1.y - p2.y) < dist_min;
+}
+
+// bound(x) of the boundary penalty, simple_tag.py:103-108 / simple_world_comm.py:167-172.
+template <typename T> __device__ __forceinline__ T arena_bound(T x) {
+    if (x < T(0.9)) return T(0);
+    if (x < T(1.0)) return (x - T(0.9)) * T(10);
+    const T e = t_exp<T>(T(2) * x - T(2));
+    return T(10) < e ? T(10) : e;   // Python min(e, 10): keeps e unless 10 < e (a NaN stays)
+}
+
+// Python's min(list) on floats: keeps the first element unless a later one compares smaller.
+template <typename T> __device__ __forceinline__ T py_min(T cur, T item) { return item < cur ? item : cur; }
+
+// One entity's World.integrate_state, multiagent/core.py:196-204.
+template <typename T, bool CLAMP>
+__device__ __forceinline__ void integrate(V2<T>& p, V2<T>& v, V2<T> force, T mass, T max_speed, T one_minus_damping, T dt) {
+    v.x = v.x * one_minus_damping;
+    v.y = v.y * one_minus_damping;
+    if (mass != T(1)) { force.x = force.x / mass; force.y = force.y / mass; }   // x / 1.0 == x
+    v.x = v.x + force.x * dt;
+    v.y = v.y + force.y * dt;
+    if (CLAMP) {
+        const T speed = t_sqrt<T>(v.x * v.x + v.y * v.y);
+        if (speed > max_speed) {
+            v.x = v.x / speed * max_speed;
+            v.y = v.y / speed * max_speed;
+        }
+    }
+    p.x = p.x + v.x * dt;
+    p.y = p.y + v.y * dt;
+}
+
+// MultiAgentEnv._set_action for a discrete int move, multiagent/environment.py:176-181,192-195.
+template <typename T> __device__ __forceinline__ V2<T> decode_move(int a, T sensitivity) {
+    V2<T> u;
+    u.x = (a == 1) ? T(-1) : ((a == 2) ? T(1) : T(0));
+    u.y = (a == 3) ? T(-1) : ((a == 4) ? T(1) : T(0));
+    u.x = u.x * sensitivity;
+    u.y = u.y * sensitivity;
+    return u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based uniform generator for on-device reset: Philox-4x32-10.
+// ---------------------------------------------------------------------------------------------
+struct Philox {
+    __host__ __device__ static inline void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __host__ __device__ static inline void block(uint64_t key, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) {
+        uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+        out[0] = (uint32_t)ctr_lo; out[1] = (uint32_t)(ctr_lo >> 32);
+        out[2] = (uint32_t)ctr_hi; out[3] = (uint32_t)(ctr_hi >> 32);
+        for (int r = 0; r < 10; ++r) {
+            round(out, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+    }
+    // 53-bit uniform in [0, 1) from two 32-bit words (same construction as numpy's random_sample).
+    __host__ __device__ static inline double u01(uint32_t a, uint32_t b) {
+        return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * (1.0 / 9007199254740992.0);
+    }
+};
+
+}  // namespace mpe

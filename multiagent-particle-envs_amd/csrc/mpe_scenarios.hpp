@@ -1,0 +1,307 @@
+// Compile-time descriptions of the small in-register scenarios and their callbacks
+// (observation / reward / benchmark_data), evaluated by one lane for one world.
+//
+// Every loop below has constant bounds and is fully unrolled, so pos[]/vel[] live in registers and
+// the observation row is written to LDS with constant offsets.  The structure of a scenario (who
+// collides, who is an adversary, which landmark is a forest) is fixed here; magnitudes (sizes,
+// accelerations, speed limits, masses, world constants) arrive at run time in SmallParams.
+#pragma once
+#include "mpe_math.hpp"
+
+namespace mpe {
+
+template <typename T, int E, int A>
+struct SmallParams {
+    T size[E];
+    T mass[A];
+    T sens[A];
+    T max_speed[A];
+    T dt, one_minus_damping, contact_force, contact_margin;
+    long long n_envs;
+};
+
+// simple_spread casts its observation to float32 (simple_spread.py:130); the float64 kernel keeps
+// that rounding so it can be compared bit for bit.
+template <typename T> __device__ __forceinline__ T round_f32(T v) { return (T)(float)v; }
+
+// ------------------------------------------------------------------------------------------
+// simple_spread with A agents and L landmarks (multiagent/scenarios/simple_spread.py)
+// ------------------------------------------------------------------------------------------
+template <int A_, int L_>
+struct SpreadCfg {
+    static constexpr int A = A_, L = L_, E = A_ + L_;
+    static constexpr int DIM_C = 0, S = 0, N_ACT = A_;
+    static constexpr int OBS_DIM = 4 + 2 * L_ + 2 * (A_ - 1);
+    static constexpr int OBS_TOTAL = A_ * OBS_DIM;
+    static constexpr int NI = A_ + 1;   // collisions per agent, occupied_landmarks
+    static constexpr int NF = A_ + 1;   // min_dists, benchmark reward per agent
+    // landmarks have collide = False (simple_spread.py:34)
+    __host__ __device__ static constexpr bool collides(int e) { return e < A_; }
+    __host__ __device__ static constexpr bool speaks(int) { return false; }
+
+    // observation(), simple_spread.py:110-130
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const P&, T* row) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            row[k++] = round_f32(vel[i].x); row[k++] = round_f32(vel[i].y);
+            row[k++] = round_f32(pos[i].x); row[k++] = round_f32(pos[i].y);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                row[k++] = round_f32(pos[A + l].x - pos[i].x);
+                row[k++] = round_f32(pos[A + l].y - pos[i].y);
+            }
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i) continue;
+                row[k++] = round_f32(pos[j].x - pos[i].x);
+                row[k++] = round_f32(pos[j].y - pos[i].y);
+            }
+        }
+    }
+
+    // reward() :83-108 and benchmark_data() :58-74
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const P& p, T* rew, bool want_info, int* info_i, T* info_f) {
+        T prox = T(0), min_dists = T(0);
+        int occupied = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            T m = norm2<T>(pos[0].x - pos[A + l].x, pos[0].y - pos[A + l].y);
+#pragma unroll
+            for (int a = 1; a < A; ++a) m = py_min<T>(m, norm2<T>(pos[a].x - pos[A + l].x, pos[a].y - pos[A + l].y));
+            prox = prox - m;
+            min_dists = min_dists + m;
+            occupied += (m < T(0.1)) ? 1 : 0;
+        }
+        bool hit[A][A];
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int j = i + 1; j < A; ++j) {
+                hit[i][j] = touching<T>(pos[i], pos[j], p.size[i] + p.size[j]);
+                hit[j][i] = hit[i][j];
+            }
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            int c = 0;
+            T bench = prox;
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                if (a == i) continue;
+                if (hit[a][i]) { c += 1; bench = bench - T(1); }
+            }
+            rew[i] = (i == 0 ? prox : T(0)) + (T)(-c);
+            if (want_info) { info_i[i] = c; info_f[1 + i] = bench; }
+        }
+        if (want_info) { info_i[A] = occupied; info_f[0] = min_dists; }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// simple_tag: 3 adversaries, 1 good agent, 2 obstacles (multiagent/scenarios/simple_tag.py)
+// ------------------------------------------------------------------------------------------
+struct TagCfg {
+    static constexpr int N_ADV = 3, A = 4, L = 2, E = 6;
+    static constexpr int DIM_C = 0, S = 0, N_ACT = 4;
+    static constexpr int OBS_ADV = 4 + 2 * L + 2 * (A - 1) + 2, OBS_GOOD = 4 + 2 * L + 2 * (A - 1);
+    static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;
+    static constexpr int NI = A, NF = 0;
+    __host__ __device__ static constexpr bool collides(int) { return true; }   // simple_tag.py:19,30
+    __host__ __device__ static constexpr bool speaks(int) { return false; }
+    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
+
+    // observation(), simple_tag.py:131-147
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const P&, T* row) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            row[k++] = vel[i].x; row[k++] = vel[i].y;
+            row[k++] = pos[i].x; row[k++] = pos[i].y;
+#pragma unroll
+            for (int l = 0; l < L; ++l) { row[k++] = pos[A + l].x - pos[i].x; row[k++] = pos[A + l].y - pos[i].y; }
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i) continue;
+                row[k++] = pos[j].x - pos[i].x; row[k++] = pos[j].y - pos[i].y;
+            }
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i || adversary(j)) continue;
+                row[k++] = vel[j].x; row[k++] = vel[j].y;
+            }
+        }
+    }
+
+    // reward() :84-129 and benchmark_data() :57-66
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const P& p, T* rew, bool want_info, int* info_i, T*) {
+        bool hit[A][N_ADV];   // hit[g][a]: good agent g touches adversary a
+        T adv_rew = T(0);
+#pragma unroll
+        for (int g = N_ADV; g < A; ++g)
+#pragma unroll
+            for (int a = 0; a < N_ADV; ++a) {
+                hit[g][a] = touching<T>(pos[g], pos[a], p.size[g] + p.size[a]);
+                if (hit[g][a]) adv_rew = adv_rew + T(10);
+            }
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            if (adversary(i)) {
+                rew[i] = adv_rew;
+                if (want_info) {
+                    int c = 0;
+#pragma unroll
+                    for (int g = N_ADV; g < A; ++g) c += hit[g][i] ? 1 : 0;
+                    info_i[i] = c;
+                }
+            } else {
+                T r = T(0);
+#pragma unroll
+                for (int a = 0; a < N_ADV; ++a) if (hit[i][a]) r = r - T(10);
+                r = r - arena_bound<T>(t_abs<T>(pos[i].x));
+                r = r - arena_bound<T>(t_abs<T>(pos[i].y));
+                rew[i] = r;
+                if (want_info) info_i[i] = 0;
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// simple_world_comm: 4 adversaries (agent 0 leads and speaks), 2 good agents; landmarks
+// [obstacle, food0, food1, forest0, forest1] (multiagent/scenarios/simple_world_comm.py:52-53)
+// ------------------------------------------------------------------------------------------
+struct WorldCommCfg {
+    static constexpr int N_ADV = 4, A = 6, L = 5, E = 11;
+    static constexpr int DIM_C = 4, S = 1, N_ACT = 7;
+    static constexpr int FOOD0 = A + 1, N_FOOD = 2, FOREST0 = A + 3;
+    static constexpr int OBS_ADV = 4 + 2 * L + 2 * (A - 1) + 2 * (A - N_ADV) + 2 + DIM_C;       // 34
+    static constexpr int OBS_GOOD = 4 + 2 * L + 2 * (A - 1) + 2 + 2 * (A - N_ADV - 1);          // 28
+    static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;                  // 192
+    static constexpr int NI = A + 2, NF = 0;
+    // only agents and the obstacle collide (simple_world_comm.py:22,34,41,48)
+    __host__ __device__ static constexpr bool collides(int e) { return e <= A; }
+    __host__ __device__ static constexpr bool speaks(int i) { return i == 0; }
+    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
+    __host__ __device__ static constexpr bool leader(int i) { return i == 0; }
+
+    template <typename T, class P>
+    __device__ static __forceinline__ void forest_bits(const V2<T> (&pos)[E], const P& p, bool (&inf)[A][2]) {
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                inf[i][f] = touching<T>(pos[i], pos[FOREST0 + f], p.size[i] + p.size[FOREST0 + f]);
+    }
+
+    // visibility test of simple_world_comm.py:254
+    __device__ static __forceinline__ bool sees(int i, bool i1, bool i2, bool o1, bool o2) {
+        return (i1 && o1) || (i2 && o2) || (!i1 && !o1 && !i2 && !o2) || leader(i);
+    }
+
+    // observation(), simple_world_comm.py:224-287
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const P& p, T* row) {
+        bool inf[A][2];
+        forest_bits<T>(pos, p, inf);
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            row[k++] = vel[i].x; row[k++] = vel[i].y;
+            row[k++] = pos[i].x; row[k++] = pos[i].y;
+#pragma unroll
+            for (int l = 0; l < L; ++l) { row[k++] = pos[A + l].x - pos[i].x; row[k++] = pos[A + l].y - pos[i].y; }
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i) continue;
+                const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
+                row[k++] = vis ? pos[j].x - pos[i].x : T(0);
+                row[k++] = vis ? pos[j].y - pos[i].y : T(0);
+            }
+            if (!adversary(i)) {   // good agents put in_forest before other_vel (:287)
+                row[k++] = inf[i][0] ? T(1) : T(-1);
+                row[k++] = inf[i][1] ? T(1) : T(-1);
+            }
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i || adversary(j)) continue;
+                const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
+                row[k++] = vis ? vel[j].x : T(0);
+                row[k++] = vis ? vel[j].y : T(0);
+            }
+            if (adversary(i)) {    // :281-285
+                row[k++] = inf[i][0] ? T(1) : T(-1);
+                row[k++] = inf[i][1] ? T(1) : T(-1);
+#pragma unroll
+                for (int c = 0; c < DIM_C; ++c) row[k++] = comm[c];
+            }
+        }
+    }
+
+    // reward() :142-198 and benchmark_data() :115-123; info also carries the integer masks.
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const P& p, T* rew, bool want_info, int* info_i, T*) {
+        bool hit[A][N_ADV];
+#pragma unroll
+        for (int g = N_ADV; g < A; ++g)
+#pragma unroll
+            for (int a = 0; a < N_ADV; ++a) hit[g][a] = touching<T>(pos[g], pos[a], p.size[g] + p.size[a]);
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            if (adversary(i)) {
+                T dmin = norm2<T>(pos[N_ADV].x - pos[i].x, pos[N_ADV].y - pos[i].y);
+#pragma unroll
+                for (int g = N_ADV + 1; g < A; ++g) dmin = py_min<T>(dmin, norm2<T>(pos[g].x - pos[i].x, pos[g].y - pos[i].y));
+                T r = T(0) - T(0.1) * dmin;
+#pragma unroll
+                for (int g = N_ADV; g < A; ++g)
+#pragma unroll
+                    for (int a = 0; a < N_ADV; ++a) if (hit[g][a]) r = r + T(5);
+                rew[i] = r;
+                if (want_info) {
+                    int c = 0;
+#pragma unroll
+                    for (int g = N_ADV; g < A; ++g) c += hit[g][i] ? 1 : 0;
+                    info_i[i] = c;
+                }
+            } else {
+                T r = T(0);
+#pragma unroll
+                for (int a = 0; a < N_ADV; ++a) if (hit[i][a]) r = r - T(5);
+                r = r - T(2) * arena_bound<T>(t_abs<T>(pos[i].x));
+                r = r - T(2) * arena_bound<T>(t_abs<T>(pos[i].y));
+                T fmin = T(0);
+#pragma unroll
+                for (int f = 0; f < N_FOOD; ++f) {
+                    const T d = norm2<T>(pos[FOOD0 + f].x - pos[i].x, pos[FOOD0 + f].y - pos[i].y);
+                    // is_collision(agent, food) uses agent - food: the squares are identical
+                    if (d < p.size[i] + p.size[FOOD0 + f]) r = r + T(2);
+                    fmin = (f == 0) ? d : py_min<T>(fmin, d);
+                }
+                r = r + T(0.05) * fmin;
+                rew[i] = r;
+                if (want_info) info_i[i] = 0;
+            }
+        }
+        if (want_info) {
+            bool inf[A][2];
+            forest_bits<T>(pos, p, inf);
+            int fb = 0, vb = 0;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                fb |= (inf[i][0] ? 1 : 0) << (2 * i);
+                fb |= (inf[i][1] ? 1 : 0) << (2 * i + 1);
+#pragma unroll
+                for (int j = 0; j < A; ++j)
+                    if (j != i && sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1])) vb |= 1 << (A * i + j);
+            }
+            info_i[A] = fb;
+            info_i[A + 1] = vb;
+        }
+    }
+};
+
+}  // namespace mpe

@@ -1,0 +1,200 @@
+// Fused step kernels for the small scenarios (simple_spread 3/3, simple_tag, simple_world_comm).
+//
+// One lane owns one world and keeps its whole state in registers: it decodes the int actions,
+// runs World.step (action force, pairwise contact force, integration, comm state) and evaluates
+// the scenario's observation / reward / info callbacks.  State is stored env-minor (SoA), so
+// state loads and stores are coalesced 256-byte rows per wave.  The per-env output rows
+// (observations, rewards, info) are env-major; each wave transposes them through LDS with an odd
+// row stride (conflict-free both ways) and streams them out as contiguous dword rows.
+//
+// A workgroup is a single 64-lane wave: the LDS tile is private to the wave, so the
+// __syncthreads() below are plain LDS waits, not hardware barriers.
+#include "mpe_scenarios.hpp"
+#include "mpe_launch.hpp"
+
+namespace mpe {
+
+enum { MODE_STEP = 0, MODE_ROLLOUT = 1, MODE_OBSERVE = 2 };
+
+// Copy `W` values per env for the wave's 64 consecutive envs from the LDS tile (row stride WS,
+// odd) to the env-major global array.  g runs over the wave's contiguous W*64-element block.
+template <typename V, int W>
+__device__ __forceinline__ void flush_rows(const V* tile, V* gdst, int lane, int nvalid) {
+    constexpr int WS = W | 1;
+#pragma unroll
+    for (int it = 0; it < W; ++it) {
+        const int g = it * 64 + lane;
+        const int row = g / W;
+        const int col = g - row * W;
+        if (row < nvalid) gdst[g] = tile[row * WS + col];
+    }
+}
+
+template <typename T, class Cfg, bool CLAMP, int MODE>
+__global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p,
+                                                   const int* __restrict__ actions, T* __restrict__ pos_g,
+                                                   T* __restrict__ vel_g, T* __restrict__ comm_g,
+                                                   T* __restrict__ obs_g, T* __restrict__ rew_g,
+                                                   uint8_t* __restrict__ done_g, int* __restrict__ info_i_g,
+                                                   T* __restrict__ info_f_g, int n_steps) {
+    constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
+    constexpr int NI = Cfg::NI, NF = Cfg::NF, DC = Cfg::DIM_C;
+    constexpr int WS_OBS = OT | 1, WS_REW = A | 1, WS_NI = NI | 1, WS_NF = (NF > 0 ? NF : 1) | 1;
+    __shared__ T tile_obs[64 * WS_OBS];
+    __shared__ T tile_rew[64 * WS_REW];
+    __shared__ int tile_ii[64 * WS_NI];
+    __shared__ T tile_if[64 * WS_NF];
+
+    const int lane = threadIdx.x;
+    const long long B = p.n_envs;
+    const long long env0 = (long long)blockIdx.x * 64;
+    const long long left = B - env0;
+    const int nvalid = left < 64 ? (int)left : 64;
+    const bool valid = lane < nvalid;
+    const long long b = valid ? env0 + lane : env0;   // idle tail lanes shadow the wave's first env
+
+    V2<T> pos[E];
+    V2<T> vel[A];
+    T comm[DC > 0 ? DC : 1];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        pos[e].x = pos_g[(long long)(2 * e) * B + b];
+        pos[e].y = pos_g[(long long)(2 * e + 1) * B + b];
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        vel[i].x = vel_g[(long long)(2 * i) * B + b];
+        vel[i].y = vel_g[(long long)(2 * i + 1) * B + b];
+    }
+    if (DC > 0) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c) comm[c] = (MODE == MODE_OBSERVE) ? comm_g[(long long)c * B + b] : T(0);
+    }
+    const bool want_info = (info_i_g != nullptr);
+
+    for (int t = 0; t < n_steps; ++t) {
+        if (MODE != MODE_OBSERVE) {
+            // ---- MultiAgentEnv._set_action: int actions -> forces and comm one-hot ----
+            const int* act = actions + ((long long)t * B + b) * NA;
+            V2<T> force[A];
+            int col = 0;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                force[i] = decode_move<T>(act[col++], p.sens[i]);     // apply_action_force: u + 0
+                if (Cfg::speaks(i)) {
+                    const int word = act[col++];
+#pragma unroll
+                    for (int c = 0; c < DC; ++c) comm[c] = (word == c) ? T(1) : T(0);   // update_agent_state
+                }
+            }
+            // ---- World.apply_environment_force: pairs in the reference's (a, b) order ----
+#pragma unroll
+            for (int a = 0; a < E; ++a) {
+#pragma unroll
+                for (int c = a + 1; c < E; ++c) {
+                    if (!Cfg::collides(a) || !Cfg::collides(c)) continue;
+                    if (a >= A && c >= A) continue;   // neither entity moves
+                    const V2<T> f = contact_force<T>(pos[a], pos[c], p.size[a] + p.size[c], p.contact_force, p.contact_margin);
+                    if (a < A) { force[a].x = f.x + force[a].x; force[a].y = f.y + force[a].y; }
+                    if (c < A) { force[c].x = -f.x + force[c].x; force[c].y = -f.y + force[c].y; }
+                }
+            }
+            // ---- World.integrate_state ----
+#pragma unroll
+            for (int i = 0; i < A; ++i)
+                integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[i], p.max_speed[i], p.one_minus_damping, p.dt);
+        }
+
+        // ---- scenario callbacks into the wave's LDS tiles ----
+        Cfg::template observe<T>(pos, vel, comm, p, tile_obs + lane * WS_OBS);
+        if (MODE != MODE_OBSERVE)
+            Cfg::template score<T>(pos, p, tile_rew + lane * WS_REW, want_info, tile_ii + lane * WS_NI, tile_if + lane * WS_NF);
+        __syncthreads();
+        const long long row0 = (long long)t * B + env0;
+        flush_rows<T, OT>(tile_obs, obs_g + row0 * OT, lane, nvalid);
+        if (MODE != MODE_OBSERVE) {
+            flush_rows<T, A>(tile_rew, rew_g + row0 * A, lane, nvalid);
+            if (valid) done_g[row0 + lane] = 0;
+            if (want_info) {
+                flush_rows<int, NI>(tile_ii, info_i_g + row0 * NI, lane, nvalid);
+                if (NF > 0 && info_f_g != nullptr) flush_rows<T, (NF > 0 ? NF : 1)>(tile_if, info_f_g + row0 * NF, lane, nvalid);
+            }
+        }
+        if (MODE == MODE_ROLLOUT) __syncthreads();   // tiles are rewritten by the next step
+    }
+
+    if (MODE != MODE_OBSERVE && valid) {
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            pos_g[(long long)(2 * i) * B + b] = pos[i].x;
+            pos_g[(long long)(2 * i + 1) * B + b] = pos[i].y;
+            vel_g[(long long)(2 * i) * B + b] = vel[i].x;
+            vel_g[(long long)(2 * i + 1) * B + b] = vel[i].y;
+        }
+        if (DC > 0) {
+#pragma unroll
+            for (int c = 0; c < DC; ++c) comm_g[(long long)c * B + b] = comm[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, class Cfg>
+static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n_envs) {
+    SmallParams<T, Cfg::E, Cfg::A> p;
+    for (int e = 0; e < Cfg::E; ++e) p.size[e] = (T)s.size[e];
+    for (int i = 0; i < Cfg::A; ++i) {
+        p.mass[i] = (T)s.mass[i];
+        p.sens[i] = (T)s.sens[i];
+        p.max_speed[i] = (T)s.max_speed[i];
+    }
+    p.dt = (T)s.dt;
+    p.one_minus_damping = (T)(1 - s.damping);   // reference evaluates (1 - damping) in float64 first
+    p.contact_force = (T)s.contact_force;
+    p.contact_margin = (T)s.contact_margin;
+    p.n_envs = n_envs;
+    return p;
+}
+
+template <typename T, class Cfg, bool CLAMP>
+static hipError_t launch_cfg(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
+    const auto p = make_params<T, Cfg>(s, B);
+    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    T* pos = (T*)a.pos; T* vel = (T*)a.vel; T* comm = (T*)a.comm; T* obs = (T*)a.obs; T* rew = (T*)a.rew; T* inf = (T*)a.info_f;
+    switch (mode) {
+        case MODE_STEP:
+            hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE_STEP>), grid, block, 0, st, p, a.actions, pos, vel, comm, obs, rew, a.done, a.info_i, inf, 1);
+            break;
+        case MODE_ROLLOUT:
+            hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE_ROLLOUT>), grid, block, 0, st, p, a.actions, pos, vel, comm, obs, rew, a.done, a.info_i, inf, a.n_steps);
+            break;
+        default:
+            hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE_OBSERVE>), grid, block, 0, st, p, a.actions, pos, vel, comm, obs, rew, a.done, a.info_i, inf, 1);
+            break;
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_small_t(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
+    const bool clamp = s.any_speed_limit();
+    switch (s.scenario) {
+        case MPE_SCN_SPREAD:
+            return clamp ? launch_cfg<T, SpreadCfg<3, 3>, true>(s, B, mode, a, st) : launch_cfg<T, SpreadCfg<3, 3>, false>(s, B, mode, a, st);
+        case MPE_SCN_TAG:
+            return launch_cfg<T, TagCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_WORLD_COMM:
+            return launch_cfg<T, WorldCommCfg, true>(s, B, mode, a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+bool small_supported(const HostSpec& s) {
+    return (s.scenario == MPE_SCN_SPREAD && s.A == 3 && s.L == 3) || s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM;
+}
+
+hipError_t launch_small(const HostSpec& s, long long B, int dtype, int mode, const StepArgs& a, hipStream_t st) {
+    return dtype == MPE_F64 ? launch_small_t<double>(s, B, mode, a, st) : launch_small_t<float>(s, B, mode, a, st);
+}
+
+}  // namespace mpe

@@ -1,0 +1,83 @@
+"""ctypes binding of libmpe_hip.so (the C ABI declared in include/mpe_hip.h).
+
+There is no CPU fallback: if the shared library is missing the import fails with
+instructions to build it, and every non-zero return code of the library is raised
+as :class:`MpeError` carrying ``mpe_last_error``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpe_hip.so")
+
+MPE_F32, MPE_F64 = 0, 1
+SCN_NONE, SCN_SPREAD, SCN_TAG, SCN_WORLD_COMM = 0, 1, 2, 3
+MAX_AGENTS = 64
+MAX_LANDMARKS = 64
+
+_p_f64 = C.POINTER(C.c_double)
+_p_u8 = C.POINTER(C.c_uint8)
+
+
+class MpeSpec(C.Structure):
+    _fields_ = [
+        ("scenario", C.c_int32), ("n_agents", C.c_int32), ("n_landmarks", C.c_int32), ("dim_c", C.c_int32),
+        ("dt", C.c_double), ("damping", C.c_double), ("contact_force", C.c_double), ("contact_margin", C.c_double),
+        ("size", _p_f64), ("mass", _p_f64), ("movable", _p_u8), ("collide", _p_u8),
+        ("sensitivity", _p_f64), ("max_speed", _p_f64), ("silent", _p_u8), ("adversary", _p_u8), ("leader", _p_u8),
+    ]
+
+
+class MpeLayout(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int64), ("n_agents", C.c_int32), ("n_landmarks", C.c_int32), ("dim_c", C.c_int32),
+        ("n_speakers", C.c_int32), ("n_act", C.c_int32), ("obs_total", C.c_int32),
+        ("n_info_i", C.c_int32), ("n_info_f", C.c_int32),
+        ("obs_dim", C.c_int32 * MAX_AGENTS), ("obs_offset", C.c_int32 * MAX_AGENTS),
+    ]
+
+
+class MpeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("mpe_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "mpe_create": (C.c_int, [C.POINTER(MpeSpec), C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mpe_destroy": (C.c_int, [C.c_void_p]),
+    "mpe_layout": (C.c_int, [C.c_void_p, C.POINTER(MpeLayout)]),
+    "mpe_last_error": (C.c_char_p, [C.c_void_p]),
+    "mpe_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]),
+    "mpe_rollout": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
+    "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "mpe_world_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmpe_hip.so once and declare the prototypes of every exported entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: the HIP library has not been built. Run `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950) at the repository root; there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in EXPORTS.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(handle, code):
+    if code != 0:
+        msg = load().mpe_last_error(handle)
+        raise MpeError(code, msg.decode() if msg else "?")

@@ -1,0 +1,149 @@
+"""Batched particle worlds resident in HBM, stepped by the HIP kernels of libmpe_hip.so.
+
+``BatchedEnv`` is the vectorised counterpart of the reference's ``MultiAgentEnv``
+(multiagent/environment.py:15-127): ``reset()`` and ``step(actions)`` act on ``n_envs``
+independent worlds at once.  All state and outputs are PyTorch tensors on one GPU; the library
+receives their raw device pointers and the current HIP stream, so nothing is copied.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spec import WorldSpec, make_spec
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BatchedEnv:
+    """n_envs worlds of one scenario.
+
+    Tensors (T = float32 or float64):
+      pos   [2E, B]  env-minor entity coordinates (agents first)     vel  [2A, B]
+      comm  [S*dim_c, B] comm state of the S speaking agents (or None)
+      obs   [B, obs_total]; ``obs_n[i]`` is the view of agent i's columns
+      rew   [B, A]    done [B] uint8    info_i [B, n_info_i] int32    info_f [B, n_info_f]
+    Actions are int32 ``[B, n_act]``: per agent its move 0..4, then its comm word if it speaks.
+    """
+
+    def __init__(self, scenario, n_envs, dtype=torch.float32, device="cuda:0", info=False, **spec_kw):
+        self.spec = scenario if isinstance(scenario, WorldSpec) else make_spec(scenario, **spec_kw)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("BatchedEnv needs a GPU device (got %s); there is no CPU path" % (device,))
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("dtype must be torch.float32 or torch.float64")
+        self.dtype = dtype
+        self.n_envs = int(n_envs)
+        self._lib = _lib.load()
+        cspec, self._keep = self.spec.to_c()
+        h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(None, self._lib.mpe_create(C.byref(cspec), self.n_envs, _lib.MPE_F64 if dtype == torch.float64 else _lib.MPE_F32,
+                                              dev_index, C.byref(h)))
+        self._h = h
+        lo = _lib.MpeLayout()
+        _lib.check(h, self._lib.mpe_layout(h, C.byref(lo)))
+        self.layout = lo
+        A, L, B = lo.n_agents, lo.n_landmarks, self.n_envs
+        self.n_agents, self.n_landmarks, self.n_act = A, L, lo.n_act
+        self.obs_dims = [lo.obs_dim[i] for i in range(A)]
+        self.obs_offsets = [lo.obs_offset[i] for i in range(A)]
+        z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
+        self.pos = z(2 * (A + L), B)
+        self.vel = z(2 * A, B)
+        self.comm = z(lo.n_speakers * lo.dim_c, B) if lo.n_speakers > 0 else None
+        self.obs = z(B, lo.obs_total)
+        self.rew = z(B, A)
+        self.done = z(B, dt=torch.uint8)
+        self.info_i = z(B, lo.n_info_i, dt=torch.int32) if info else None
+        self.info_f = z(B, lo.n_info_f) if (info and lo.n_info_f > 0) else None
+        self._episode = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.mpe_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def obs_n(self):
+        """Per-agent observation views ``[B, obs_dim[i]]`` (the reference's obs_n list)."""
+        return [self.obs[:, o:o + d] for o, d in zip(self.obs_offsets, self.obs_dims)]
+
+    def observe(self):
+        """Scenario.observation for every agent of every env on the current state."""
+        _lib.check(self._h, self._lib.mpe_observe(self._h, _ptr(self.pos), _ptr(self.vel), _ptr(self.comm), _ptr(self.obs), self._stream()))
+        return self.obs
+
+    def reset(self, seed=0, mask=None):
+        """Scenario.reset_world on device (all envs, or those with a non-zero mask byte)."""
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        _lib.check(self._h, self._lib.mpe_reset(self._h, int(seed), self._episode, _ptr(mask), _ptr(self.pos), _ptr(self.vel),
+                                                _ptr(self.comm), self._stream()))
+        self._episode += 1
+        return self.observe()
+
+    def _actions(self, actions, lead):
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dtype != torch.int32:
+            a = a.to(torch.int32)
+        a = a.contiguous()
+        want = tuple(lead) + (self.n_envs, self.n_act)
+        if tuple(a.shape) != want:
+            raise ValueError("actions must have shape %s, got %s" % (want, tuple(a.shape)))
+        return a
+
+    def step(self, actions):
+        """MultiAgentEnv.step for the whole batch.  Returns (obs, rew, done, info) tensors that are
+        overwritten by the next call."""
+        a = self._actions(actions, ())
+        _lib.check(self._h, self._lib.mpe_step(self._h, _ptr(a), _ptr(self.pos), _ptr(self.vel), _ptr(self.comm), _ptr(self.obs),
+                                               _ptr(self.rew), _ptr(self.done), _ptr(self.info_i), _ptr(self.info_f), self._stream()))
+        return self.obs, self.rew, self.done, (self.info_i, self.info_f)
+
+    def rollout(self, actions, out=None):
+        """``T`` steps in one launch for pre-computed actions ``[T, B, n_act]``.  Returns a dict of
+        ``[T, ...]`` tensors (pass the previous result as ``out`` to reuse its buffers)."""
+        T = int(actions.shape[0])
+        a = self._actions(actions, (T,))
+        lo, B = self.layout, self.n_envs
+        if out is None or out["obs"].shape[0] != T:
+            z = lambda *shape, dt=self.dtype: torch.empty(*shape, dtype=dt, device=self.device)
+            out = {"obs": z(T, B, lo.obs_total), "rew": z(T, B, self.n_agents), "done": z(T, B, dt=torch.uint8),
+                   "info_i": z(T, B, lo.n_info_i, dt=torch.int32) if self.info_i is not None else None,
+                   "info_f": z(T, B, lo.n_info_f) if self.info_f is not None else None}
+        _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), _ptr(self.pos), _ptr(self.vel), _ptr(self.comm), _ptr(out["obs"]),
+                                                  _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]), _ptr(out["info_f"]), T,
+                                                  self._stream()))
+        return out
+
+    # ------------------------------------------------------------------
+    def set_state(self, pos, vel, comm=None):
+        """Inject a state given env-major: pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c]."""
+        B, A, L = self.n_envs, self.n_agents, self.n_landmarks
+        pos = torch.as_tensor(np.asarray(pos), dtype=self.dtype).reshape(B, 2 * (A + L))
+        vel = torch.as_tensor(np.asarray(vel), dtype=self.dtype).reshape(B, 2 * A)
+        self.pos.copy_(pos.t().contiguous())
+        self.vel.copy_(vel.t().contiguous())
+        if self.comm is not None:
+            if comm is None:
+                self.comm.zero_()
+            else:
+                self.comm.copy_(torch.as_tensor(np.asarray(comm), dtype=self.dtype).reshape(B, -1).t().contiguous())
+
+    def get_state(self):
+        """Returns env-major numpy copies (pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c] or None)."""
+        B, A, L = self.n_envs, self.n_agents, self.n_landmarks
+        pos = self.pos.t().reshape(B, A + L, 2).cpu().numpy()
+        vel = self.vel.t().reshape(B, A, 2).cpu().numpy()
+        comm = self.comm.t().cpu().numpy() if self.comm is not None else None
+        return pos, vel, comm

@@ -1,0 +1,94 @@
+"""Static world descriptions (what ``Scenario.make_world`` builds) for the batched simulator."""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class WorldSpec:
+    """Per-entity properties and world constants of one scenario, agents first then landmarks
+    (the order of ``World.entities``, multiagent/core.py:127-129)."""
+
+    scenario: int
+    n_agents: int
+    n_landmarks: int
+    dim_c: int
+    size: np.ndarray
+    mass: np.ndarray
+    movable: np.ndarray
+    collide: np.ndarray
+    sensitivity: np.ndarray      # Agent.accel or 5.0 when None (multiagent/environment.py:192-195)
+    max_speed: np.ndarray        # +inf when Entity.max_speed is None (multiagent/core.py:199)
+    silent: np.ndarray
+    adversary: np.ndarray
+    leader: np.ndarray
+    # World.__init__ defaults, multiagent/core.py:117-124
+    dt: float = 0.1
+    damping: float = 0.25
+    contact_force: float = 1e2
+    contact_margin: float = 1e-3
+    name: str = ""
+
+    def to_c(self):
+        """Returns (MpeSpec, keepalive) -- keepalive owns the arrays the struct points into."""
+        E, A = self.n_agents + self.n_landmarks, self.n_agents
+        f64 = lambda a, n: np.ascontiguousarray(np.asarray(a, np.float64).reshape(n))
+        u8 = lambda a, n: np.ascontiguousarray(np.asarray(a, bool).astype(np.uint8).reshape(n))
+        arrs = dict(size=f64(self.size, E), mass=f64(self.mass, E), movable=u8(self.movable, E), collide=u8(self.collide, E),
+                    sensitivity=f64(self.sensitivity, A), max_speed=f64(self.max_speed, A), silent=u8(self.silent, A),
+                    adversary=u8(self.adversary, A), leader=u8(self.leader, A))
+        s = _lib.MpeSpec(scenario=self.scenario, n_agents=A, n_landmarks=self.n_landmarks, dim_c=self.dim_c,
+                         dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin)
+        for k, a in arrs.items():
+            ptr_t = _lib._p_f64 if a.dtype == np.float64 else _lib._p_u8
+            setattr(s, k, a.ctypes.data_as(ptr_t))
+        return s, arrs
+
+
+def spread_spec(n_agents=3, n_landmarks=3):
+    """simple_spread (multiagent/scenarios/simple_spread.py:8-38): agents of size 0.15 that collide
+    and are silent, default acceleration (sensitivity 5.0), no speed limit; landmarks of the default
+    size 0.05 that neither move nor collide.  The reference fixes 3/3; both counts are free here."""
+    A, L = n_agents, n_landmarks
+    return WorldSpec(_lib.SCN_SPREAD, A, L, 2,
+                     size=np.r_[np.full(A, 0.15), np.full(L, 0.05)], mass=np.ones(A + L),
+                     movable=np.r_[np.ones(A, bool), np.zeros(L, bool)], collide=np.r_[np.ones(A, bool), np.zeros(L, bool)],
+                     sensitivity=np.full(A, 5.0), max_speed=np.full(A, np.inf), silent=np.ones(A, bool),
+                     adversary=np.zeros(A, bool), leader=np.zeros(A, bool), name="simple_spread")
+
+
+def tag_spec():
+    """simple_tag (multiagent/scenarios/simple_tag.py:7-36): 3 adversaries (size .075, accel 3,
+    max_speed 1) chase 1 good agent (size .05, accel 4, max_speed 1.3) around 2 obstacles (size .2)."""
+    adv = np.array([True, True, True, False])
+    return WorldSpec(_lib.SCN_TAG, 4, 2, 2,
+                     size=np.r_[np.where(adv, 0.075, 0.05), [0.2, 0.2]], mass=np.ones(6),
+                     movable=np.r_[np.ones(4, bool), np.zeros(2, bool)], collide=np.ones(6, bool),
+                     sensitivity=np.where(adv, 3.0, 4.0), max_speed=np.where(adv, 1.0, 1.3), silent=np.ones(4, bool),
+                     adversary=adv, leader=np.zeros(4, bool), name="simple_tag")
+
+
+def world_comm_spec():
+    """simple_world_comm (multiagent/scenarios/simple_world_comm.py:7-57): 4 adversaries (agent 0
+    is the leader and the only speaker, dim_c 4) and 2 good agents (size .045); landmarks are
+    [obstacle .2 (collides), food .03 x2, forest .3 x2] in that order (:52-53)."""
+    adv = np.array([True] * 4 + [False] * 2)
+    leader = np.arange(6) == 0
+    return WorldSpec(_lib.SCN_WORLD_COMM, 6, 5, 4,
+                     size=np.r_[np.where(adv, 0.075, 0.045), [0.2, 0.03, 0.03, 0.3, 0.3]], mass=np.ones(11),
+                     movable=np.r_[np.ones(6, bool), np.zeros(5, bool)],
+                     collide=np.r_[np.ones(6, bool), [True, False, False, False, False]],
+                     sensitivity=np.where(adv, 3.0, 4.0), max_speed=np.where(adv, 1.0, 1.3), silent=~leader,
+                     adversary=adv, leader=leader, name="simple_world_comm")
+
+
+def make_spec(name, **kw):
+    if name == "simple_spread":
+        return spread_spec(**kw)
+    if name == "simple_tag":
+        return tag_spec()
+    if name == "simple_world_comm":
+        return world_comm_spec()
+    raise ValueError("no batched kernel for scenario %r" % (name,))

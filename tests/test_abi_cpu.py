@@ -1,0 +1,64 @@
+"""CPU-side checks of the boundary: the shared library loads, exports every symbol declared in
+include/mpe_hip.h, and the ctypes structure mirrors agree with the header."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mpe_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpe_[a-z_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    for n in ("mpe_create", "mpe_destroy", "mpe_layout", "mpe_last_error", "mpe_step", "mpe_rollout",
+              "mpe_observe", "mpe_reset", "mpe_world_step"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    from mpe_hip import _lib
+    lib = _lib.load()
+    for name in _declared():
+        assert hasattr(lib, name), name
+        assert name in _lib.EXPORTS, "binding is missing a prototype for " + name
+
+
+def test_struct_mirrors_match_header_sizes():
+    from mpe_hip import _lib
+    # MpeSpec: 4 int32 + 4 double + 9 pointers ; MpeLayout: int64 + 8 int32 + 2 * 64 int32
+    assert C.sizeof(_lib.MpeSpec) == 16 + 32 + 9 * 8
+    assert C.sizeof(_lib.MpeLayout) == 8 + 8 * 4 + 2 * 64 * 4
+
+
+def test_create_rejects_bad_arguments_without_a_gpu():
+    from mpe_hip import _lib, spread_spec
+    lib = _lib.load()
+    spec, keep = spread_spec().to_c()
+    h = C.c_void_p()
+    assert lib.mpe_create(C.byref(spec), 0, _lib.MPE_F32, 0, C.byref(h)) == -1
+    assert b"n_envs" in lib.mpe_last_error(None)
+    assert lib.mpe_create(C.byref(spec), 8, 7, 0, C.byref(h)) == -1
+    assert lib.mpe_create(None, 8, 0, 0, C.byref(h)) == -1
+
+
+def test_specs_match_oracle_specs():
+    """The product's scenario tables and the oracle's were written separately; they must agree."""
+    import numpy as np
+    import mpe_oracle as orc
+    from mpe_hip import make_spec
+    for name, kw_p, kw_o in (("simple_spread", {}, {}), ("simple_spread", dict(n_agents=64, n_landmarks=64), dict(A=64, L=64)),
+                             ("simple_tag", {}, {}), ("simple_world_comm", {}, {})):
+        p, o = make_spec(name, **kw_p), orc.make_spec(name, **kw_o)
+        assert (p.n_agents, p.n_landmarks, p.dim_c) == (o.A, o.L, o.dim_c)
+        for a, b in ((p.size, o.size), (p.mass, o.mass), (p.movable, o.movable), (p.collide, o.collide),
+                     (p.sensitivity, o.sens), (p.max_speed, o.max_speed), (p.silent, o.silent),
+                     (p.adversary, o.adversary), (p.leader, o.leader)):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        assert (p.dt, p.damping, p.contact_force, p.contact_margin) == (o.dt, o.damping, o.contact_force, o.contact_margin)

@@ -1,0 +1,198 @@
+"""HIP kernels against the golden fixtures (reference outputs) and the numpy oracle.
+
+Bars: float64 kernels within 1e-9 (relative, with a 1e-12 absolute floor) of the reference after
+25 free-running steps; float32 kernels within 1e-4; integer fields (collision counts, occupied
+landmarks, forest / visibility masks, done) bit-exact for float64.  For float32 an integer field
+may legitimately differ where a distance sits within float32 rounding of its threshold, so those
+are compared only on envs whose float64 margin to every threshold exceeds 1e-5.
+"""
+import numpy as np
+import pytest
+
+import mpe_oracle as orc
+from conftest import GOLDEN_CASES, load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+SMALL_CASES = ["spread3", "tag", "world_comm"]
+
+
+def _env(case, B, dtype, info=True):
+    import mpe_hip
+    scn, kw = GOLDEN_CASES[case]
+    kw = {("n_agents" if k == "A" else "n_landmarks"): v for k, v in kw.items()}
+    return mpe_hip.BatchedEnv(scn, B, dtype=dtype, device="cuda:0", info=info, **kw)
+
+
+def _close(a, b, rtol, atol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def _unpack_info(case, env, info_i, info_f):
+    A = env.n_agents
+    ii = info_i.cpu().numpy()
+    out = {"collisions": ii[:, :A]}
+    if case.startswith("spread"):
+        ff = info_f.cpu().numpy()
+        out.update(occupied=ii[:, A], min_dists=ff[:, 0], info_rew=ff[:, 1:1 + A])
+    if case == "world_comm":
+        fb, vb = ii[:, A], ii[:, A + 1]
+        out["in_forest"] = np.stack([np.stack([(fb >> (2 * i + f)) & 1 for f in range(2)], 1) for i in range(A)], 1)
+        out["visible"] = np.stack([np.stack([(vb >> (A * i + j)) & 1 for j in range(A)], 1) for i in range(A)], 1)
+    return out
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_fp64_trajectory_matches_reference(case):
+    g = load_golden(case)
+    T, B, _ = g["actions"].shape
+    env = _env(case, B, torch.float64)
+    env.set_state(g["pos0"], g["vel0"])
+    A = env.n_agents
+    for t in range(T):
+        obs, rew, done, (info_i, info_f) = env.step(torch.as_tensor(g["actions"][t]))
+        pos, vel, comm = env.get_state()
+        assert _close(pos[:, :A], g["pos"][t], 1e-9, 1e-12), (case, t, np.abs(pos[:, :A] - g["pos"][t]).max())
+        assert _close(vel, g["vel"][t], 1e-9, 1e-12), (case, t)
+        assert _close(obs.cpu().numpy(), g["obs"][t], 1e-6 if case == "spread3" else 1e-9, 1e-12), (case, t)
+        assert _close(rew.cpu().numpy(), g["rew"][t], 1e-9, 1e-12), (case, t)
+        assert not done.any()
+        inf = _unpack_info(case, env, info_i, info_f)
+        assert np.array_equal(inf["collisions"], g["collisions"][t]), (case, t)
+        if case == "spread3":
+            assert np.array_equal(inf["occupied"], g["occupied"][t])
+            assert _close(inf["min_dists"], g["min_dists"][t], 1e-9, 1e-12)
+            assert _close(inf["info_rew"], g["info_rew"][t], 1e-9, 1e-12)
+        if case == "world_comm":
+            assert np.array_equal(inf["in_forest"], g["in_forest"][t])
+            assert np.array_equal(inf["visible"], g["visible"][t])
+            assert np.array_equal(comm, g["comm"][t])
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_fp64_single_step_is_bit_exact_from_reference_state(case):
+    """Teacher-forced: each step starts from the reference's own state, so the only differences
+    left are the device's exp/log1p last-place roundings; integer fields must match exactly."""
+    g = load_golden(case)
+    T, B, _ = g["actions"].shape
+    scn, kw = GOLDEN_CASES[case]
+    A = orc.make_spec(scn, **kw).A
+    env = _env(case, B, torch.float64)
+    pos_prev = g["pos0"].copy()
+    vel_prev = g["vel0"]
+    worst = 0.0
+    for t in range(T):
+        env.set_state(pos_prev, vel_prev)
+        obs, rew, done, (info_i, info_f) = env.step(torch.as_tensor(g["actions"][t]))
+        pos, vel, _ = env.get_state()
+        worst = max(worst, np.abs(pos[:, :A] - g["pos"][t]).max(), np.abs(vel - g["vel"][t]).max())
+        assert np.array_equal(_unpack_info(case, env, info_i, info_f)["collisions"], g["collisions"][t])
+        pos_prev = pos_prev.copy()
+        pos_prev[:, :A] = g["pos"][t]
+        vel_prev = g["vel"][t]
+    assert worst < 1e-13, worst
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_fp32_trajectory_within_1e4(case):
+    g = load_golden(case)
+    T, B, _ = g["actions"].shape
+    env = _env(case, B, torch.float32)
+    env.set_state(g["pos0"], g["vel0"])
+    A = env.n_agents
+    for t in range(T):
+        obs, rew, done, (info_i, info_f) = env.step(torch.as_tensor(g["actions"][t]))
+    pos, vel, _ = env.get_state()
+    assert _close(pos[:, :A], g["pos"][T - 1], 1e-4, 1e-4), np.abs(pos[:, :A] - g["pos"][T - 1]).max()
+    assert _close(vel, g["vel"][T - 1], 1e-4, 1e-4)
+    assert _close(obs.cpu().numpy(), g["obs"][T - 1], 1e-4, 1e-4)
+    # rewards contain +-5/10 jumps at collision thresholds: compare where the counts agree
+    same = np.all(_unpack_info(case, env, info_i, info_f)["collisions"] == g["collisions"][T - 1], axis=1)
+    assert same.mean() > 0.9
+    assert _close(rew.cpu().numpy()[same], g["rew"][T - 1][same], 1e-4, 2e-4)
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_rollout_equals_repeated_step(case, dtype):
+    dt = getattr(torch, dtype)
+    g = load_golden(case)
+    T, B, _ = g["actions"].shape
+    a = torch.as_tensor(g["actions"]).to("cuda:0")
+    e1, e2 = _env(case, B, dt), _env(case, B, dt)
+    e1.set_state(g["pos0"], g["vel0"])
+    e2.set_state(g["pos0"], g["vel0"])
+    out = e2.rollout(a)
+    for t in range(T):
+        obs, rew, done, (ii, ff) = e1.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t])
+        assert torch.equal(ii, out["info_i"][t]) and torch.equal(done, out["done"][t])
+        if ff is not None:
+            assert torch.equal(ff, out["info_f"][t])
+    assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.vel, e2.vel)
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_large_batch_fp64_against_oracle(case):
+    """B is not a multiple of the 64-lane wave; 25 free-running steps against the oracle."""
+    scn, kw = GOLDEN_CASES[case]
+    spec = orc.make_spec(scn, **kw)
+    B = 4096 + 37
+    rng = np.random.RandomState(7)
+    pos, vel, _ = orc.reset(spec, rng, 1)
+    pos = np.concatenate([rng.uniform(-1, 1, (B, spec.A, 2)), rng.uniform(-0.9, 0.9, (B, spec.L, 2))], axis=1)
+    vel = np.zeros((B, spec.A, 2))
+    env = _env(case, B, torch.float64)
+    env.set_state(pos, vel)
+    for t in range(25):
+        act = rng.randint(0, 5, (B, spec.n_act))
+        if scn == "simple_world_comm":
+            act[:, 1] = rng.randint(0, 4, B)
+        obs, rew, done, (ii, ff) = env.step(torch.as_tensor(act, dtype=torch.int32))
+        pos, vel, comm, o_obs, o_rew, _ = orc.env_step(spec, pos, vel, act)
+    g_pos, g_vel, _ = env.get_state()
+    assert _close(g_pos, pos, 1e-9, 1e-12), np.abs(g_pos - pos).max()
+    assert _close(g_vel, vel, 1e-9, 1e-12)
+    tol_obs = 1e-6 if scn == "simple_spread" else 1e-9
+    assert _close(obs.cpu().numpy(), np.concatenate(o_obs, 1), tol_obs, 1e-12)
+    inf = orc.info(spec, pos)
+    got = ii.cpu().numpy()[:, :spec.A]
+    assert np.array_equal(got, inf["collisions"])
+    assert _close(rew.cpu().numpy(), o_rew, 1e-9, 1e-12)
+
+
+def test_observe_matches_oracle_and_reset_distribution():
+    import mpe_hip
+    for scn in ("simple_spread", "simple_tag", "simple_world_comm"):
+        spec = orc.make_spec(scn)
+        env = mpe_hip.BatchedEnv(scn, 1000, dtype=torch.float64, device="cuda:0")
+        obs = env.reset(seed=3).cpu().numpy()
+        pos, vel, comm = env.get_state()
+        assert np.abs(pos[:, :spec.A]).max() <= 1.0 and np.abs(vel).max() == 0
+        lim = 1.0 if scn == "simple_spread" else 0.9
+        assert np.abs(pos[:, spec.A:]).max() <= lim
+        assert abs(pos.mean()) < 0.05 and pos[:, :spec.A].std() == pytest.approx(1 / np.sqrt(3), rel=0.05)
+        c = np.zeros((1000, spec.A, spec.dim_c))
+        want = np.concatenate(orc.observe(spec, pos, vel, c), 1)
+        assert _close(obs, want, 1e-6 if scn == "simple_spread" else 0, 0)
+        # a second reset draws a different episode; a masked reset leaves unmasked envs alone
+        mask = torch.zeros(1000, dtype=torch.uint8)
+        mask[::2] = 1
+        env.reset(seed=3, mask=mask)
+        pos2, _, _ = env.get_state()
+        assert np.array_equal(pos2[1::2], pos[1::2]) and not np.array_equal(pos2[::2], pos[::2])
+
+
+def test_errors_are_loud():
+    import mpe_hip
+    with pytest.raises(mpe_hip.MpeError):
+        mpe_hip.BatchedEnv("simple_spread", 0)
+    env = mpe_hip.BatchedEnv("simple_spread", 8)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(8, 4, dtype=torch.int32))
+    bad = mpe_hip.tag_spec()
+    bad.adversary = np.array([True, False, True, False])
+    with pytest.raises(mpe_hip.MpeError):
+        mpe_hip.BatchedEnv(bad, 8)
