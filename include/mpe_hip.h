@@ -92,7 +92,8 @@ typedef struct MpeLayout {
     int32_t n_info_i;    /* simple_spread: A collision counts + occupied_landmarks;
                             simple_tag: A collision counts;
                             simple_world_comm: A collision counts + in_forest bits (bit 2i+f)
-                            + visibility bits (bit A*i+j) */
+                            + visibility bits (agent i sees its k-th other agent, others in
+                            ascending order skipping i: bit (A-1)*i+k) */
     int32_t n_info_f;    /* simple_spread: min_dists + A benchmark rewards; otherwise 0 */
     int32_t obs_dim[MPE_MAX_AGENTS];
     int32_t obs_offset[MPE_MAX_AGENTS];

@@ -296,7 +296,7 @@ struct WorldCommCfg {
                 fb |= (inf[i][1] ? 1 : 0) << (2 * i + 1);
 #pragma unroll
                 for (int j = 0; j < A; ++j)
-                    if (j != i && sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1])) vb |= 1 << (A * i + j);
+                    if (j != i && sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1])) vb |= 1 << ((A - 1) * i + (j > i ? j - 1 : j));
             }
             info_i[A] = fb;
             info_i[A + 1] = vb;

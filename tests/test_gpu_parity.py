@@ -40,7 +40,8 @@ def _unpack_info(case, env, info_i, info_f):
     if case == "world_comm":
         fb, vb = ii[:, A], ii[:, A + 1]
         out["in_forest"] = np.stack([np.stack([(fb >> (2 * i + f)) & 1 for f in range(2)], 1) for i in range(A)], 1)
-        out["visible"] = np.stack([np.stack([(vb >> (A * i + j)) & 1 for j in range(A)], 1) for i in range(A)], 1)
+        out["visible"] = np.stack([np.stack([((vb >> ((A - 1) * i + (j - 1 if j > i else j))) & 1) * (i != j) for j in range(A)], 1)
+                                   for i in range(A)], 1)
     return out
 
 
