@@ -1,8 +1,10 @@
 // Scalar building blocks of the particle-world step, shared by every kernel.
 //
-// Everything here is written so that the float64 instantiation performs the same IEEE operations
-// in the same order as the reference's numpy scalar code (compile with -ffp-contract=off so no
-// multiply-add is fused); the float32 instantiation is the throughput variant.
+// The generic templates perform the same IEEE operations in the same order as the reference's numpy
+// scalar code (compile with -ffp-contract=off so no multiply-add is fused); they are what the
+// float64 kernels run.  The float specialisations are the throughput variant: same formulas on the
+// hardware's 1-ulp v_rsq/v_rcp/v_sqrt/v_exp/v_log instructions with fused multiply-adds, good to
+// float32 rounding (trajectory bar 1e-4 after 25 steps) but not bit-faithful.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,15 +14,16 @@ namespace mpe {
 template <typename T> struct V2 { T x, y; };
 
 template <typename T> __device__ __forceinline__ T t_sqrt(T v);
-template <> __device__ __forceinline__ float t_sqrt<float>(float v) { return sqrtf(v); }
+template <> __device__ __forceinline__ float t_sqrt<float>(float v) { return __builtin_amdgcn_sqrtf(v); }
 template <> __device__ __forceinline__ double t_sqrt<double>(double v) { return sqrt(v); }
 
 template <typename T> __device__ __forceinline__ T t_exp(T v);
-template <> __device__ __forceinline__ float t_exp<float>(float v) { return expf(v); }
+template <> __device__ __forceinline__ float t_exp<float>(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896340736f); }
 template <> __device__ __forceinline__ double t_exp<double>(double v) { return exp(v); }
 
 template <typename T> __device__ __forceinline__ T t_log1p(T v);
-template <> __device__ __forceinline__ float t_log1p<float>(float v) { return log1pf(v); }
+// v >= 0 here (v = exp(-|y|)); the absolute error of log(1 + v) stays below one float ulp of 1
+template <> __device__ __forceinline__ float t_log1p<float>(float v) { return __builtin_amdgcn_logf(1.0f + v) * 0.693147180559945309417f; }
 template <> __device__ __forceinline__ double t_log1p<double>(double v) { return log1p(v); }
 
 template <typename T> __device__ __forceinline__ T t_abs(T v);
@@ -29,6 +32,7 @@ template <> __device__ __forceinline__ double t_abs<double>(double v) { return f
 
 // sqrt(sum(square(delta))) of a 2-vector: multiagent/core.py:224 and every is_collision.
 template <typename T> __device__ __forceinline__ T norm2(T dx, T dy) { return t_sqrt<T>(dx * dx + dy * dy); }
+template <> __device__ __forceinline__ float norm2<float>(float dx, float dy) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(dx, dx, dy * dy)); }
 
 // numpy.logaddexp(0, y) (npy_logaddexp): y == 0 -> ln 2; y < 0 -> log1p(exp(y));
 // y > 0 -> y + log1p(exp(-y)); NaN propagates.  multiagent/core.py:229.
@@ -53,6 +57,24 @@ __device__ __forceinline__ V2<T> contact_force(V2<T> pa, V2<T> pb, T dist_min, T
     V2<T> f;
     f.x = cf * dx / dist * pen;
     f.y = cf * dy / dist * pen;
+    return f;
+}
+
+// float32: one v_rsq gives both dist and 1/dist; the divisions by dist and by k become multiplies.
+// dist == 0 -> rsq = inf -> dist = 0 * inf = NaN, so the NaN of the reference is kept.
+template <>
+__device__ __forceinline__ V2<float> contact_force<float>(V2<float> pa, V2<float> pb, float dist_min, float cf, float k) {
+    const float dx = pa.x - pb.x, dy = pa.y - pb.y;
+    const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+    const float inv = __builtin_amdgcn_rsqf(d2);
+    const float dist = d2 * inv;
+    const float y = (dist_min - dist) * __builtin_amdgcn_rcpf(k);
+    const float e = __builtin_amdgcn_exp2f(-fabsf(y) * 1.44269504088896340736f);
+    const float sp = fmaxf(y, 0.0f) + __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309417f;
+    const float s = cf * inv * (sp * k);
+    V2<float> f;
+    f.x = dx * s;
+    f.y = dy * s;
     return f;
 }
 
@@ -91,6 +113,25 @@ __device__ __forceinline__ void integrate(V2<T>& p, V2<T>& v, V2<T> force, T mas
     p.x = p.x + v.x * dt;
     p.y = p.y + v.y * dt;
 }
+
+template <bool CLAMP>
+__device__ __forceinline__ void integrate_f32(V2<float>& p, V2<float>& v, V2<float> force, float mass, float max_speed, float one_minus_damping, float dt) {
+    if (mass != 1.0f) { const float im = __builtin_amdgcn_rcpf(mass); force.x *= im; force.y *= im; }
+    v.x = __builtin_fmaf(force.x, dt, v.x * one_minus_damping);
+    v.y = __builtin_fmaf(force.y, dt, v.y * one_minus_damping);
+    if (CLAMP) {
+        const float s2 = __builtin_fmaf(v.x, v.x, v.y * v.y);
+        if (s2 > max_speed * max_speed) {
+            const float sc = max_speed * __builtin_amdgcn_rsqf(s2);
+            v.x *= sc;
+            v.y *= sc;
+        }
+    }
+    p.x = __builtin_fmaf(v.x, dt, p.x);
+    p.y = __builtin_fmaf(v.y, dt, p.y);
+}
+template <> __device__ __forceinline__ void integrate<float, true>(V2<float>& p, V2<float>& v, V2<float> f, float m, float ms, float omd, float dt) { integrate_f32<true>(p, v, f, m, ms, omd, dt); }
+template <> __device__ __forceinline__ void integrate<float, false>(V2<float>& p, V2<float>& v, V2<float> f, float m, float ms, float omd, float dt) { integrate_f32<false>(p, v, f, m, ms, omd, dt); }
 
 // MultiAgentEnv._set_action for a discrete int move, multiagent/environment.py:176-181,192-195.
 template <typename T> __device__ __forceinline__ V2<T> decode_move(int a, T sensitivity) {

@@ -4,10 +4,10 @@
 // runs World.step (action force, pairwise contact force, integration, comm state) and evaluates
 // the scenario's observation / reward / info callbacks.  State is stored env-minor (SoA), so
 // state loads and stores are coalesced 256-byte rows per wave.  The per-env output rows
-// (observations, rewards, info) are env-major; each wave transposes them through LDS with an odd
-// row stride (conflict-free both ways) and streams them out as contiguous dword rows.
+// (observations, rewards, info) are env-major; each wave transposes them through LDS and streams
+// them out as contiguous 16-byte vectors.
 //
-// A workgroup is a single 64-lane wave: the LDS tile is private to the wave, so the
+// A workgroup is a single 64-lane wave: the LDS tiles are private to the wave, so the
 // __syncthreads() below are plain LDS waits, not hardware barriers.
 #include "mpe_scenarios.hpp"
 #include "mpe_launch.hpp"
@@ -16,19 +16,48 @@ namespace mpe {
 
 enum { MODE_STEP = 0, MODE_ROLLOUT = 1, MODE_OBSERVE = 2 };
 
-// Copy `W` values per env for the wave's 64 consecutive envs from the LDS tile (row stride WS,
-// odd) to the env-major global array.  g runs over the wave's contiguous W*64-element block.
-template <typename V, int W>
-__device__ __forceinline__ void flush_rows(const V* tile, V* gdst, int lane, int nvalid) {
-    constexpr int WS = W | 1;
+// ---- wave-private LDS tile holding W values for each of the wave's 64 consecutive envs ----------
+// Lane l writes its env's row, then the wave streams the tile to the env-major global array.
+//
+// LINEAR: rows are stored back to back (row stride W), i.e. the tile is a byte image of the wave's
+//   contiguous 64*W-element block of the global array, which goes out as 16-byte vectors with no
+//   index arithmetic.  Row writes then land with lane stride W: fine when W*sizeof(V)/4 is not a
+//   multiple of a large power of two (simple_spread 42, simple_tag 62: 2-way, free for ds_write).
+// PADDED: row stride W|1 (odd) keeps both directions conflict-free for any W (simple_world_comm:
+//   192 values per row would otherwise be a 32-way conflict) at the price of a divide per element.
+template <typename V, int W, bool LINEAR>
+struct Tile {
+    static constexpr int STRIDE = LINEAR ? W : (W | 1);
+    static constexpr int SIZE = 64 * STRIDE;
+    static constexpr int VEC = 16 / (int)sizeof(V);
+
+    __device__ static __forceinline__ V* row(V* tile, int lane) { return tile + lane * STRIDE; }
+
+    // full: all 64 envs valid and gdst 16-byte aligned (wave-uniform)
+    __device__ static __forceinline__ void flush(const V* tile, V* gdst, int lane, int nvalid, bool full) {
+        if (LINEAR && full) {
+            typedef V VT __attribute__((ext_vector_type(VEC)));
+            constexpr int NV = 64 * W / VEC, FULL_IT = NV / 64, REM = NV % 64;
+            const VT* src = reinterpret_cast<const VT*>(tile);
+            VT* dst = reinterpret_cast<VT*>(gdst);
 #pragma unroll
-    for (int it = 0; it < W; ++it) {
-        const int g = it * 64 + lane;
-        const int row = g / W;
-        const int col = g - row * W;
-        if (row < nvalid) gdst[g] = tile[row * WS + col];
+            for (int it = 0; it < FULL_IT; ++it) dst[it * 64 + lane] = src[it * 64 + lane];
+            if (REM > 0 && lane < REM) dst[FULL_IT * 64 + lane] = src[FULL_IT * 64 + lane];
+        } else {
+            const int n = nvalid * W;
+#pragma unroll
+            for (int it = 0; it < W; ++it) {
+                const int g = it * 64 + lane;
+                if (LINEAR) {
+                    if (g < n) gdst[g] = tile[g];
+                } else {
+                    const int r = g / W;
+                    if (g < n) gdst[g] = tile[r * STRIDE + (g - r * W)];
+                }
+            }
+        }
     }
-}
+};
 
 template <typename T, class Cfg, bool CLAMP, int MODE>
 __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p,
@@ -38,12 +67,16 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                                                    uint8_t* __restrict__ done_g, int* __restrict__ info_i_g,
                                                    T* __restrict__ info_f_g, int n_steps) {
     constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
-    constexpr int NI = Cfg::NI, NF = Cfg::NF, DC = Cfg::DIM_C;
-    constexpr int WS_OBS = OT | 1, WS_REW = A | 1, WS_NI = NI | 1, WS_NF = (NF > 0 ? NF : 1) | 1;
-    __shared__ T tile_obs[64 * WS_OBS];
-    __shared__ T tile_rew[64 * WS_REW];
-    __shared__ int tile_ii[64 * WS_NI];
-    __shared__ T tile_if[64 * WS_NF];
+    constexpr int NI = Cfg::NI, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C;
+    constexpr bool LIN = ((OT * (int)sizeof(T) / 4) % 16) != 0;
+    using ObsTile = Tile<T, OT, LIN>;
+    using RewTile = Tile<T, A, true>;
+    using IiTile = Tile<int, NI, true>;
+    using IfTile = Tile<T, NF, true>;
+    __shared__ __attribute__((aligned(16))) T tile_obs[ObsTile::SIZE];
+    __shared__ __attribute__((aligned(16))) T tile_rew[RewTile::SIZE];
+    __shared__ __attribute__((aligned(16))) int tile_ii[IiTile::SIZE];
+    __shared__ __attribute__((aligned(16))) T tile_if[IfTile::SIZE];
 
     const int lane = threadIdx.x;
     const long long B = p.n_envs;
@@ -52,6 +85,9 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     const int nvalid = left < 64 ? (int)left : 64;
     const bool valid = lane < nvalid;
     const long long b = valid ? env0 + lane : env0;   // idle tail lanes shadow the wave's first env
+    // every per-step output block of this wave starts at element (t*B + env0) * W: 16-byte aligned
+    // for all t and W when B is a multiple of 4 (env0 is a multiple of 64)
+    const bool full = (nvalid == 64) && ((B & 3) == 0);
 
     V2<T> pos[E];
     V2<T> vel[A];
@@ -72,10 +108,22 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     }
     const bool want_info = (info_i_g != nullptr);
 
+    // actions of the step about to run; the next step's are fetched while this one computes
+    int act[NA];
+    if (MODE != MODE_OBSERVE) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) act[j] = actions[b * NA + j];
+    }
+
     for (int t = 0; t < n_steps; ++t) {
         if (MODE != MODE_OBSERVE) {
+            int act_next[NA];
+            if (MODE == MODE_ROLLOUT) {
+                const long long tn = (t + 1 < n_steps) ? t + 1 : t;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) act_next[j] = actions[(tn * B + b) * NA + j];
+            }
             // ---- MultiAgentEnv._set_action: int actions -> forces and comm one-hot ----
-            const int* act = actions + ((long long)t * B + b) * NA;
             V2<T> force[A];
             int col = 0;
 #pragma unroll
@@ -103,21 +151,25 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 #pragma unroll
             for (int i = 0; i < A; ++i)
                 integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[i], p.max_speed[i], p.one_minus_damping, p.dt);
+            if (MODE == MODE_ROLLOUT) {
+#pragma unroll
+                for (int j = 0; j < NA; ++j) act[j] = act_next[j];
+            }
         }
 
         // ---- scenario callbacks into the wave's LDS tiles ----
-        Cfg::template observe<T>(pos, vel, comm, p, tile_obs + lane * WS_OBS);
+        Cfg::template observe<T>(pos, vel, comm, p, ObsTile::row(tile_obs, lane));
         if (MODE != MODE_OBSERVE)
-            Cfg::template score<T>(pos, p, tile_rew + lane * WS_REW, want_info, tile_ii + lane * WS_NI, tile_if + lane * WS_NF);
+            Cfg::template score<T>(pos, p, RewTile::row(tile_rew, lane), want_info, IiTile::row(tile_ii, lane), IfTile::row(tile_if, lane));
         __syncthreads();
         const long long row0 = (long long)t * B + env0;
-        flush_rows<T, OT>(tile_obs, obs_g + row0 * OT, lane, nvalid);
+        ObsTile::flush(tile_obs, obs_g + row0 * OT, lane, nvalid, full);
         if (MODE != MODE_OBSERVE) {
-            flush_rows<T, A>(tile_rew, rew_g + row0 * A, lane, nvalid);
+            RewTile::flush(tile_rew, rew_g + row0 * A, lane, nvalid, full);
             if (valid) done_g[row0 + lane] = 0;
             if (want_info) {
-                flush_rows<int, NI>(tile_ii, info_i_g + row0 * NI, lane, nvalid);
-                if (NF > 0 && info_f_g != nullptr) flush_rows<T, (NF > 0 ? NF : 1)>(tile_if, info_f_g + row0 * NF, lane, nvalid);
+                IiTile::flush(tile_ii, info_i_g + row0 * NI, lane, nvalid, full);
+                if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::flush(tile_if, info_f_g + row0 * NF, lane, nvalid, full);
             }
         }
         if (MODE == MODE_ROLLOUT) __syncthreads();   // tiles are rewritten by the next step

@@ -62,6 +62,8 @@ class BatchedEnv:
         self.info_i = z(B, lo.n_info_i, dt=torch.int32) if info else None
         self.info_f = z(B, lo.n_info_f) if (info and lo.n_info_f > 0) else None
         self._episode = 0
+        # raw device pointers of the persistent buffers, resolved once (the tensors are never reallocated)
+        self._p = {k: _ptr(getattr(self, k)) for k in ("pos", "vel", "comm", "obs", "rew", "done", "info_i", "info_f")}
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -80,23 +82,25 @@ class BatchedEnv:
 
     def observe(self):
         """Scenario.observation for every agent of every env on the current state."""
-        _lib.check(self._h, self._lib.mpe_observe(self._h, _ptr(self.pos), _ptr(self.vel), _ptr(self.comm), _ptr(self.obs), self._stream()))
+        p = self._p
+        _lib.check(self._h, self._lib.mpe_observe(self._h, p["pos"], p["vel"], p["comm"], p["obs"], self._stream()))
         return self.obs
 
-    def reset(self, seed=0, mask=None):
-        """Scenario.reset_world on device (all envs, or those with a non-zero mask byte)."""
+    def reset(self, seed=0, mask=None, observe=True):
+        """Scenario.reset_world on device (all envs, or those with a non-zero mask byte).  Returns
+        the fresh observations like MultiAgentEnv.reset unless ``observe`` is False."""
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
-        _lib.check(self._h, self._lib.mpe_reset(self._h, int(seed), self._episode, _ptr(mask), _ptr(self.pos), _ptr(self.vel),
-                                                _ptr(self.comm), self._stream()))
+        p = self._p
+        _lib.check(self._h, self._lib.mpe_reset(self._h, int(seed), self._episode, _ptr(mask), p["pos"], p["vel"], p["comm"],
+                                                self._stream()))
         self._episode += 1
-        return self.observe()
+        return self.observe() if observe else None
 
     def _actions(self, actions, lead):
-        a = torch.as_tensor(actions, device=self.device)
-        if a.dtype != torch.int32:
-            a = a.to(torch.int32)
-        a = a.contiguous()
+        a = actions
+        if not (torch.is_tensor(a) and a.dtype == torch.int32 and a.device == self.device and a.is_contiguous()):
+            a = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
         want = tuple(lead) + (self.n_envs, self.n_act)
         if tuple(a.shape) != want:
             raise ValueError("actions must have shape %s, got %s" % (want, tuple(a.shape)))
@@ -106,8 +110,9 @@ class BatchedEnv:
         """MultiAgentEnv.step for the whole batch.  Returns (obs, rew, done, info) tensors that are
         overwritten by the next call."""
         a = self._actions(actions, ())
-        _lib.check(self._h, self._lib.mpe_step(self._h, _ptr(a), _ptr(self.pos), _ptr(self.vel), _ptr(self.comm), _ptr(self.obs),
-                                               _ptr(self.rew), _ptr(self.done), _ptr(self.info_i), _ptr(self.info_f), self._stream()))
+        p = self._p
+        _lib.check(self._h, self._lib.mpe_step(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["obs"], p["rew"], p["done"],
+                                               p["info_i"], p["info_f"], self._stream()))
         return self.obs, self.rew, self.done, (self.info_i, self.info_f)
 
     def rollout(self, actions, out=None):
@@ -121,7 +126,8 @@ class BatchedEnv:
             out = {"obs": z(T, B, lo.obs_total), "rew": z(T, B, self.n_agents), "done": z(T, B, dt=torch.uint8),
                    "info_i": z(T, B, lo.n_info_i, dt=torch.int32) if self.info_i is not None else None,
                    "info_f": z(T, B, lo.n_info_f) if self.info_f is not None else None}
-        _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), _ptr(self.pos), _ptr(self.vel), _ptr(self.comm), _ptr(out["obs"]),
+        p = self._p
+        _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], _ptr(out["obs"]),
                                                   _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]), _ptr(out["info_f"]), T,
                                                   self._stream()))
         return out
