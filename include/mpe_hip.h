@@ -21,6 +21,10 @@
  *   pos      T[2E][B]        row 2e+d holds coordinate d of entity e for every env (env-minor)
  *   vel      T[2A][B]        same for agent velocities (landmarks never move)
  *   comm     T[S*dim_c][B]   state.c of the S non-silent agents, in agent order (may be NULL if S == 0)
+ *     Small worlds (one lane simulates one world) keep this env-minor layout so that a wave's 64
+ *     worlds load as coalesced rows.  Worlds simulated by a whole wave (MpeLayout.state_env_major
+ *     == 1: simple_spread other than 3/3, and MPE_SCN_NONE) store the state arrays transposed,
+ *     pos T[B][2E], vel T[B][2A], comm T[B][S*dim_c], so that one world is contiguous.
  *   actions  int32[B][n_act] per env, the reference's action_n list flattened: for each agent its
  *                            move int 0..4, followed by its comm int 0..dim_c-1 if it is not silent
  *   obs      T[B][obs_total] per env, the agents' observation vectors concatenated in agent order;
@@ -95,6 +99,8 @@ typedef struct MpeLayout {
                             + visibility bits (agent i sees its k-th other agent, others in
                             ascending order skipping i: bit (A-1)*i+k) */
     int32_t n_info_f;    /* simple_spread: min_dists + A benchmark rewards; otherwise 0 */
+    int32_t state_env_major; /* 0: pos/vel/comm are [rows][B]; 1: [B][rows] (see "Memory layout") */
+    int32_t reserved;
     int32_t obs_dim[MPE_MAX_AGENTS];
     int32_t obs_offset[MPE_MAX_AGENTS];
 } MpeLayout;
@@ -146,9 +152,10 @@ int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask
               void* vel, void* comm, mpe_stream_t stream);
 
 /*
- * World.step alone (core.py:142-158) for scenarios whose callbacks stay in Python: forces u
- * T[2A][B] (already scaled, i.e. agent.action.u) and comm actions c T[S*dim_c][B] are given
- * directly; pos, vel, comm are updated in place.
+ * World.step alone (core.py:142-158) for scenarios whose callbacks stay in Python (handles created
+ * with MPE_SCN_NONE, env-major state): forces u T[B][2A] (already scaled, i.e. agent.action.u) and
+ * comm actions c T[B][S*dim_c] (agent.action.c of the speakers, may be NULL if S == 0) are given
+ * directly; pos, vel, comm are updated in place.  Walls are not simulated.
  */
 int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* vel, void* comm,
                    mpe_stream_t stream);

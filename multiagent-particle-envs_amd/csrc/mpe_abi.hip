@@ -16,6 +16,8 @@ struct MpeHandle {
     MpeLayout layout;
     int dtype;
     int device;
+    bool use_wave;          // wave-per-world kernels, env-major state
+    DevTable* table;        // device copy of the per-entity table (wave kernels only)
     char err[512];
 };
 
@@ -152,15 +154,34 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     h->dtype = dtype;
     h->device = device;
     fill_layout(s, n_envs, &h->layout);
-    if (s.scenario != MPE_SCN_NONE && !small_supported(s)) {
+    h->use_wave = !small_supported(s);
+    if (h->use_wave && !wave_supported(s)) {
         delete h;
         return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: no kernel for scenario %d with %d agents / %d landmarks", s.scenario, A, L);
+    }
+    h->layout.state_env_major = h->use_wave ? 1 : 0;
+    if (h->use_wave) {
+        if (n_envs > 0x7fffffffLL) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: at most 2^31-1 envs for this scenario size"); }
+        DevTable t;
+        memset(&t, 0, sizeof(t));
+        for (int k = 0; k < A + L; ++k) { t.size[k] = s.size[k]; t.mass[k] = s.mass[k]; t.collide[k] = s.collide[k]; t.movable[k] = s.movable[k]; }
+        for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; }
+        if ((e = hipSetDevice(device)) != hipSuccess || (e = hipMalloc((void**)&h->table, sizeof(DevTable))) != hipSuccess ||
+            (e = hipMemcpy(h->table, &t, sizeof(DevTable), hipMemcpyHostToDevice)) != hipSuccess) {
+            if (h->table) (void)hipFree(h->table);
+            delete h;
+            return hip_fail(nullptr, e, "mpe_create: device table");
+        }
     }
     *out = h;
     return MPE_OK;
 }
 
 int mpe_destroy(MpeHandle* h) {
+    if (h && h->table) {
+        (void)hipSetDevice(h->device);
+        (void)hipFree(h->table);
+    }
     delete h;
     return MPE_OK;
 }
@@ -183,7 +204,8 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
     if (a.info_f && !a.info_i) return fail(h, MPE_ERR_INVALID, "%s: info_f requires info_i", who);
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
-    e = launch_small(h->spec, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream);
+    e = h->use_wave ? launch_wave(h->spec, h->table, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream)
+                    : launch_small(h->spec, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, who);
     return MPE_OK;
 }
@@ -213,15 +235,22 @@ int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask
     if (comm_rows > 0 && !comm) return fail(h, MPE_ERR_INVALID, "mpe_reset: comm must not be NULL for a scenario with speaking agents");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
-    e = launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, seed, episode, mask, pos, vel, comm, (hipStream_t)stream);
+    e = launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, h->use_wave, seed, episode, mask, pos, vel, comm, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, "mpe_reset");
     return MPE_OK;
 }
 
 int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* vel, void* comm, mpe_stream_t stream) {
-    (void)u; (void)c; (void)pos; (void)vel; (void)comm; (void)stream;
     if (!h) return MPE_ERR_INVALID;
-    return fail(h, MPE_ERR_UNSUPPORTED, "mpe_world_step: not built yet");
+    if (h->spec.scenario != MPE_SCN_NONE) return fail(h, MPE_ERR_INVALID, "mpe_world_step: handle must be created with MPE_SCN_NONE");
+    if (!u || !pos || !vel) return fail(h, MPE_ERR_INVALID, "mpe_world_step: u, pos and vel must not be NULL");
+    const int rows = h->layout.n_speakers * h->spec.dim_c;
+    if (rows > 0 && (!c || !comm)) return fail(h, MPE_ERR_INVALID, "mpe_world_step: c and comm must not be NULL for a world with speaking agents");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
+    e = launch_world_step(h->spec, h->table, h->layout.n_envs, h->dtype, u, c, pos, vel, comm, rows, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(h, e, "mpe_world_step");
+    return MPE_OK;
 }
 
 }  // extern "C"

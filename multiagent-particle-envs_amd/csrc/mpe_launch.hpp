@@ -25,6 +25,13 @@ struct HostSpec {
     }
 };
 
+// Per-entity table in device memory, read by the run-time driven (wave-per-world) kernels.
+struct DevTable {
+    double size[MAX_E], mass[MAX_E];
+    double sens[MPE_MAX_AGENTS], max_speed[MPE_MAX_AGENTS];
+    uint8_t collide[MAX_E], movable[MAX_E], silent[MPE_MAX_AGENTS];
+};
+
 struct StepArgs {
     const int32_t* actions;
     void *pos, *vel, *comm, *obs, *rew;
@@ -41,7 +48,13 @@ hipError_t launch_small(const HostSpec& s, long long n_envs, int dtype, int mode
 }  // namespace mpe
 
 namespace mpe {
-// on-device reset_world (mpe_reset.hip)
-hipError_t launch_reset(const HostSpec& s, long long n_envs, int dtype, int comm_rows, unsigned long long seed,
+// on-device reset_world (mpe_reset.hip); env_major selects the state layout
+hipError_t launch_reset(const HostSpec& s, long long n_envs, int dtype, int comm_rows, bool env_major, unsigned long long seed,
                         unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, hipStream_t st);
+
+// wave-per-world kernels (mpe_wave.hip), env-major state; mode: 0 step, 1 rollout, 2 observe
+bool wave_supported(const HostSpec& s);
+hipError_t launch_wave(const HostSpec& s, const DevTable* table, long long n_envs, int dtype, int mode, const StepArgs& a, hipStream_t st);
+hipError_t launch_world_step(const HostSpec& s, const DevTable* table, long long n_envs, int dtype, const void* u, const void* c,
+                             void* pos, void* vel, void* comm, int n_speak_rows, hipStream_t st);
 }  // namespace mpe

@@ -1,0 +1,226 @@
+// Wave-per-world kernels for worlds too large for one lane's registers (up to 64 agents and 64
+// landmarks), driven by a run-time per-entity table.
+//
+// One 64-lane wave owns one world.  Entity positions, agent velocities and the per-entity
+// properties are staged in LDS; lane i integrates agent i, walking its contact partners in
+// ascending entity order (the accumulation order of the reference's pair loop, so float64 sums are
+// bit-identical), and reads each partner's position as an LDS broadcast.  For these worlds the
+// state is stored env-major (one world's 2E coordinates are contiguous), so a wave's loads and
+// stores of its world are single coalesced rows, and the observation block of a world
+// (A x (4 + 2L + 2(A-1)) values) is produced element-parallel across the lanes and streamed out
+// contiguously.
+//
+// Epilogues: EPI_NONE  -- World.step only; forces and comm actions come in as arrays
+//            EPI_SPREAD -- int actions in, simple_spread observation / reward / benchmark_data out
+#include "mpe_launch.hpp"
+#include "mpe_math.hpp"
+
+namespace mpe {
+
+enum { EPI_NONE = 0, EPI_SPREAD = 1 };
+enum { WMODE_STEP = 0, WMODE_OBSERVE = 2 };
+
+template <typename T>
+struct WaveParams {
+    const DevTable* table;
+    T dt, one_minus_damping, contact_force, contact_margin;
+    long long n_envs;
+    int A, L, dim_c, n_speak_rows;
+};
+
+template <typename T> __device__ __forceinline__ T spread_round(T v) { return (T)(float)v; }
+
+template <typename T, int EPI, int MODE, bool CLAMP>
+__global__ __launch_bounds__(64) void wave_kernel(const WaveParams<T> p, const int* __restrict__ actions,
+                                                  const T* __restrict__ u_g, const T* __restrict__ c_g,
+                                                  T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ comm_g,
+                                                  T* __restrict__ obs_g, T* __restrict__ rew_g, uint8_t* __restrict__ done_g,
+                                                  int* __restrict__ info_i_g, T* __restrict__ info_f_g, int n_steps) {
+    __shared__ V2<T> P[MAX_E];          // entity positions, agents first
+    __shared__ V2<T> Vel[MPE_MAX_AGENTS];
+    __shared__ T size_s[MAX_E];
+    __shared__ int coll_idx[MAX_E];     // indices of the colliding entities, ascending
+    __shared__ T mind_s[MPE_MAX_LANDMARKS];
+    __shared__ int n_coll_s;
+
+    const int lane = threadIdx.x;
+    const int A = p.A, L = p.L, E = A + L;
+    const long long b = blockIdx.x;
+    const long long B = p.n_envs;
+    const DevTable* tb = p.table;
+
+    // ---- stage the world ----
+    for (int e = lane; e < E; e += 64) {
+        P[e].x = pos_g[b * (2 * E) + 2 * e];
+        P[e].y = pos_g[b * (2 * E) + 2 * e + 1];
+        size_s[e] = (T)tb->size[e];
+    }
+    if (lane < A) {
+        Vel[lane].x = vel_g[b * (2 * A) + 2 * lane];
+        Vel[lane].y = vel_g[b * (2 * A) + 2 * lane + 1];
+    }
+    if (lane == 0) {
+        int n = 0;
+        for (int e = 0; e < E; ++e)
+            if (tb->collide[e]) coll_idx[n++] = e;
+        n_coll_s = n;
+    }
+    __syncthreads();
+    const int n_coll = n_coll_s;
+    const bool is_agent = lane < A;
+    const int me = is_agent ? lane : 0;
+    const bool i_collide = tb->collide[me] != 0;
+    const T my_size = size_s[me];
+    const T my_mass = (T)tb->mass[me];
+    const T my_sens = (T)tb->sens[me];
+    const T my_max_speed = (T)tb->max_speed[me];
+    const bool want_info = (info_i_g != nullptr);
+    const int OD = 4 + 2 * L + 2 * (A - 1);      // simple_spread observation length
+
+    for (int t = 0; t < n_steps; ++t) {
+        const long long row = (long long)t * B + b;
+        if (MODE != WMODE_OBSERVE) {
+            V2<T> pi = P[me], vi = Vel[me];
+            // ---- action force ----
+            V2<T> f;
+            if (EPI == EPI_SPREAD) {
+                const int a = is_agent ? actions[row * A + lane] : 0;
+                f = decode_move<T>(a, my_sens);                       // environment.py:176-195
+            } else {
+                f.x = is_agent ? u_g[b * (2 * A) + 2 * lane] : T(0);  // agent.action.u as given
+                f.y = is_agent ? u_g[b * (2 * A) + 2 * lane + 1] : T(0);
+            }
+            // ---- contact forces: partners in ascending entity order (core.py:170-181) ----
+            if (i_collide) {
+                for (int k = 0; k < n_coll; ++k) {
+                    const int j = coll_idx[k];
+                    if (j == me) continue;
+                    const V2<T> g = contact_force<T>(pi, P[j], my_size + size_s[j], p.contact_force, p.contact_margin);
+                    f.x = g.x + f.x;
+                    f.y = g.y + f.y;
+                }
+            }
+            integrate<T, CLAMP>(pi, vi, f, my_mass, my_max_speed, p.one_minus_damping, p.dt);   // core.py:193-204
+            __syncthreads();            // every lane has read the old positions
+            if (is_agent) { P[lane] = pi; Vel[lane] = vi; }
+            __syncthreads();
+            if (EPI == EPI_NONE) {
+                // update_agent_state (core.py:206-212): speakers copy their comm action
+                for (int r = lane; r < p.n_speak_rows; r += 64) comm_g[b * p.n_speak_rows + r] = c_g[b * p.n_speak_rows + r];
+            }
+        }
+
+        if (EPI == EPI_SPREAD) {
+            // ---- observation(), simple_spread.py:110-130: rows of OD/2 coordinate pairs ----
+            const int RP = OD / 2, total = A * RP;
+            const float inv_rp = 1.0f / (float)RP;    // q <= 64 * 129: (q + 0.5) / RP floors exactly in float
+            T* obs_env = obs_g + row * (long long)(A * OD);
+            for (int q = lane; q < total; q += 64) {
+                const int i = (int)(((float)q + 0.5f) * inv_rp), r = q - i * RP;
+                V2<T> o;
+                if (r == 0) o = Vel[i];
+                else if (r == 1) o = P[i];
+                else {
+                    int src;
+                    if (r < 2 + L) src = A + (r - 2);
+                    else { const int m = r - 2 - L; src = m + (m >= i ? 1 : 0); }
+                    o.x = P[src].x - P[i].x;
+                    o.y = P[src].y - P[i].y;
+                }
+                obs_env[2 * q] = spread_round<T>(o.x);
+                obs_env[2 * q + 1] = spread_round<T>(o.y);
+            }
+            if (MODE != WMODE_OBSERVE) {
+                // ---- reward() :83-108 and benchmark_data() :58-74 ----
+                if (lane < L) {
+                    const V2<T> pl = P[A + lane];
+                    T m = norm2<T>(P[0].x - pl.x, P[0].y - pl.y);
+                    for (int a = 1; a < A; ++a) m = py_min<T>(m, norm2<T>(P[a].x - pl.x, P[a].y - pl.y));
+                    mind_s[lane] = m;
+                }
+                __syncthreads();
+                T prox = T(0), min_dists = T(0);
+                int occupied = 0;
+                for (int l = 0; l < L; ++l) {           // every lane repeats the short ordered sum
+                    const T m = mind_s[l];
+                    prox = prox - m;
+                    min_dists = min_dists + m;
+                    occupied += (m < T(0.1)) ? 1 : 0;
+                }
+                if (is_agent) {
+                    int c = 0;
+                    T bench = prox;
+                    const V2<T> pi = P[lane];
+                    for (int a = 0; a < A; ++a) {
+                        if (a == lane) continue;
+                        if (touching<T>(P[a], pi, size_s[a] + my_size)) { c += 1; bench = bench - T(1); }
+                    }
+                    rew_g[row * A + lane] = (lane == 0 ? prox : T(0)) + (T)(-c);
+                    if (want_info) {
+                        info_i_g[row * (A + 1) + lane] = c;
+                        if (info_f_g) info_f_g[row * (A + 1) + 1 + lane] = bench;
+                    }
+                }
+                if (lane == 0) {
+                    done_g[row] = 0;
+                    if (want_info) {
+                        info_i_g[row * (A + 1) + A] = occupied;
+                        if (info_f_g) info_f_g[row * (A + 1)] = min_dists;
+                    }
+                }
+                __syncthreads();        // mind_s is rewritten by the next step
+            }
+        }
+    }
+
+    if (MODE != WMODE_OBSERVE && is_agent) {
+        pos_g[b * (2 * E) + 2 * lane] = P[lane].x;
+        pos_g[b * (2 * E) + 2 * lane + 1] = P[lane].y;
+        vel_g[b * (2 * A) + 2 * lane] = Vel[lane].x;
+        vel_g[b * (2 * A) + 2 * lane + 1] = Vel[lane].y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int EPI, int MODE>
+static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long long B, const StepArgs& a, const void* u, const void* c,
+                                int n_speak_rows, hipStream_t st) {
+    WaveParams<T> p;
+    p.table = table;
+    p.dt = (T)s.dt;
+    p.one_minus_damping = (T)(1 - s.damping);
+    p.contact_force = (T)s.contact_force;
+    p.contact_margin = (T)s.contact_margin;
+    p.n_envs = B;
+    p.A = s.A; p.L = s.L; p.dim_c = s.dim_c; p.n_speak_rows = n_speak_rows;
+    const dim3 grid((unsigned)B), block(64);
+    if (s.any_speed_limit())
+        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, true>), grid, block, 0, st, p, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
+                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
+    else
+        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false>), grid, block, 0, st, p, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
+                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
+    return hipGetLastError();
+}
+
+bool wave_supported(const HostSpec& s) { return s.scenario == MPE_SCN_SPREAD || s.scenario == MPE_SCN_NONE; }
+
+// mode: 0 step, 1 rollout, 2 observe (scenario handles); physics-only when u is given
+hipError_t launch_wave(const HostSpec& s, const DevTable* table, long long B, int dtype, int mode, const StepArgs& a, hipStream_t st) {
+    if (B > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (mode == 2)
+        return dtype == MPE_F64 ? launch_wave_t<double, EPI_SPREAD, WMODE_OBSERVE>(s, table, B, a, nullptr, nullptr, 0, st)
+                                : launch_wave_t<float, EPI_SPREAD, WMODE_OBSERVE>(s, table, B, a, nullptr, nullptr, 0, st);
+    return dtype == MPE_F64 ? launch_wave_t<double, EPI_SPREAD, WMODE_STEP>(s, table, B, a, nullptr, nullptr, 0, st)
+                            : launch_wave_t<float, EPI_SPREAD, WMODE_STEP>(s, table, B, a, nullptr, nullptr, 0, st);
+}
+
+hipError_t launch_world_step(const HostSpec& s, const DevTable* table, long long B, int dtype, const void* u, const void* c, void* pos,
+                             void* vel, void* comm, int n_speak_rows, hipStream_t st) {
+    if (B > 0x7fffffffLL) return hipErrorInvalidValue;
+    const StepArgs a{nullptr, pos, vel, comm, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    return dtype == MPE_F64 ? launch_wave_t<double, EPI_NONE, WMODE_STEP>(s, table, B, a, u, c, n_speak_rows, st)
+                            : launch_wave_t<float, EPI_NONE, WMODE_STEP>(s, table, B, a, u, c, n_speak_rows, st);
+}
+
+}  // namespace mpe

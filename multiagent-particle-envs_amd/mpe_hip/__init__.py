@@ -1,4 +1,4 @@
 """mpe_hip: MI355X-native batched multi-agent particle worlds."""
 from ._lib import MpeError  # noqa: F401
-from .spec import WorldSpec, make_spec, spread_spec, tag_spec, world_comm_spec  # noqa: F401
+from .spec import WorldSpec, make_spec, physics_spec, spread_spec, tag_spec, world_comm_spec  # noqa: F401
 from .batch import BatchedEnv  # noqa: F401

@@ -32,7 +32,7 @@ class MpeLayout(C.Structure):
     _fields_ = [
         ("n_envs", C.c_int64), ("n_agents", C.c_int32), ("n_landmarks", C.c_int32), ("dim_c", C.c_int32),
         ("n_speakers", C.c_int32), ("n_act", C.c_int32), ("obs_total", C.c_int32),
-        ("n_info_i", C.c_int32), ("n_info_f", C.c_int32),
+        ("n_info_i", C.c_int32), ("n_info_f", C.c_int32), ("state_env_major", C.c_int32), ("reserved", C.c_int32),
         ("obs_dim", C.c_int32 * MAX_AGENTS), ("obs_offset", C.c_int32 * MAX_AGENTS),
     ]
 

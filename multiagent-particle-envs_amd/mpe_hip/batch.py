@@ -24,6 +24,8 @@ class BatchedEnv:
     Tensors (T = float32 or float64):
       pos   [2E, B]  env-minor entity coordinates (agents first)     vel  [2A, B]
       comm  [S*dim_c, B] comm state of the S speaking agents (or None)
+      (worlds simulated by a whole wave -- ``env_major`` is True -- store these transposed:
+      pos [B, 2E], vel [B, 2A], comm [B, S*dim_c]; use get_state / set_state to stay layout-agnostic)
       obs   [B, obs_total]; ``obs_n[i]`` is the view of agent i's columns
       rew   [B, A]    done [B] uint8    info_i [B, n_info_i] int32    info_f [B, n_info_f]
     Actions are int32 ``[B, n_act]``: per agent its move 0..4, then its comm word if it speaks.
@@ -53,9 +55,11 @@ class BatchedEnv:
         self.obs_dims = [lo.obs_dim[i] for i in range(A)]
         self.obs_offsets = [lo.obs_offset[i] for i in range(A)]
         z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
-        self.pos = z(2 * (A + L), B)
-        self.vel = z(2 * A, B)
-        self.comm = z(lo.n_speakers * lo.dim_c, B) if lo.n_speakers > 0 else None
+        self.env_major = bool(lo.state_env_major)
+        st = (lambda rows: z(B, rows)) if self.env_major else (lambda rows: z(rows, B))
+        self.pos = st(2 * (A + L))
+        self.vel = st(2 * A)
+        self.comm = st(lo.n_speakers * lo.dim_c) if lo.n_speakers > 0 else None
         self.obs = z(B, lo.obs_total)
         self.rew = z(B, A)
         self.done = z(B, dt=torch.uint8)
@@ -136,20 +140,34 @@ class BatchedEnv:
     def set_state(self, pos, vel, comm=None):
         """Inject a state given env-major: pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c]."""
         B, A, L = self.n_envs, self.n_agents, self.n_landmarks
+        lay = (lambda x: x.contiguous()) if self.env_major else (lambda x: x.t().contiguous())
         pos = torch.as_tensor(np.asarray(pos), dtype=self.dtype).reshape(B, 2 * (A + L))
         vel = torch.as_tensor(np.asarray(vel), dtype=self.dtype).reshape(B, 2 * A)
-        self.pos.copy_(pos.t().contiguous())
-        self.vel.copy_(vel.t().contiguous())
+        self.pos.copy_(lay(pos))
+        self.vel.copy_(lay(vel))
         if self.comm is not None:
             if comm is None:
                 self.comm.zero_()
             else:
-                self.comm.copy_(torch.as_tensor(np.asarray(comm), dtype=self.dtype).reshape(B, -1).t().contiguous())
+                self.comm.copy_(lay(torch.as_tensor(np.asarray(comm), dtype=self.dtype).reshape(B, -1)))
 
     def get_state(self):
         """Returns env-major numpy copies (pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c] or None)."""
         B, A, L = self.n_envs, self.n_agents, self.n_landmarks
-        pos = self.pos.t().reshape(B, A + L, 2).cpu().numpy()
-        vel = self.vel.t().reshape(B, A, 2).cpu().numpy()
-        comm = self.comm.t().cpu().numpy() if self.comm is not None else None
+        lay = (lambda x: x) if self.env_major else (lambda x: x.t())
+        pos = lay(self.pos).reshape(B, A + L, 2).cpu().numpy()
+        vel = lay(self.vel).reshape(B, A, 2).cpu().numpy()
+        comm = lay(self.comm).cpu().numpy() if self.comm is not None else None
         return pos, vel, comm
+
+    def world_step(self, u, c=None):
+        """World.step alone (multiagent/core.py:142-158) for a physics-only handle (scenario id
+        SCN_NONE): ``u`` [B, 2A] are the agents' already-scaled action forces (agent.action.u) and
+        ``c`` [B, S*dim_c] the speakers' comm actions.  State is updated in place."""
+        u = torch.as_tensor(u, dtype=self.dtype, device=self.device).reshape(self.n_envs, 2 * self.n_agents).contiguous()
+        if self.comm is not None:
+            c = torch.as_tensor(c, dtype=self.dtype, device=self.device).reshape(self.n_envs, -1).contiguous()
+        else:
+            c = None
+        p = self._p
+        _lib.check(self._h, self._lib.mpe_world_step(self._h, _ptr(u), _ptr(c), p["pos"], p["vel"], p["comm"], self._stream()))

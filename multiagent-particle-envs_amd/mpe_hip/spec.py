@@ -84,6 +84,17 @@ def world_comm_spec():
                      adversary=adv, leader=leader, name="simple_world_comm")
 
 
+def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, **world):
+    """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158); the
+    scenario's observation / reward callbacks stay with the caller."""
+    A, L = n_agents, n_landmarks
+    return WorldSpec(_lib.SCN_NONE, A, L, dim_c, size=np.asarray(size, float), mass=np.asarray(mass, float),
+                     movable=np.r_[np.ones(A, bool), np.zeros(L, bool)], collide=np.asarray(collide, bool),
+                     sensitivity=np.asarray(sensitivity, float), max_speed=np.asarray(max_speed, float),
+                     silent=np.asarray(silent, bool), adversary=np.zeros(A, bool), leader=np.zeros(A, bool),
+                     name="physics", **world)
+
+
 def make_spec(name, **kw):
     if name == "simple_spread":
         return spread_spec(**kw)

@@ -197,3 +197,117 @@ def test_errors_are_loud():
     bad.adversary = np.array([True, False, True, False])
     with pytest.raises(mpe_hip.MpeError):
         mpe_hip.BatchedEnv(bad, 8)
+
+
+# ------------------------------------------------------------------------------------------
+# wave-per-world kernels: scaled simple_spread (64 agents / 64 landmarks) and physics-only step
+# ------------------------------------------------------------------------------------------
+def test_spread64_fp64_trajectory_matches_reference():
+    g = load_golden("spread64")
+    T, B, A = g["actions"].shape
+    env = _env("spread64", B, torch.float64)
+    assert env.env_major
+    env.set_state(g["pos0"], g["vel0"])
+    obs_steps = list(g["obs_steps"])
+    for t in range(T):
+        obs, rew, done, (info_i, info_f) = env.step(torch.as_tensor(g["actions"][t]))
+        pos, vel, _ = env.get_state()
+        assert _close(pos[:, :A], g["pos"][t], 1e-9, 1e-12), (t, np.abs(pos[:, :A] - g["pos"][t]).max())
+        assert _close(vel, g["vel"][t], 1e-9, 1e-12), t
+        assert _close(rew.cpu().numpy(), g["rew"][t], 1e-9, 1e-12), t
+        inf = _unpack_info("spread64", env, info_i, info_f)
+        assert np.array_equal(inf["collisions"], g["collisions"][t]), t
+        assert np.array_equal(inf["occupied"], g["occupied"][t])
+        assert _close(inf["min_dists"], g["min_dists"][t], 1e-9, 1e-12)
+        assert _close(inf["info_rew"], g["info_rew"][t], 1e-9, 1e-12)
+        if t in obs_steps:
+            assert _close(obs.cpu().numpy(), g["obs"][obs_steps.index(t)], 1e-6, 1e-12), t
+
+
+def test_spread64_fp32_single_step_within_1e4():
+    """64 overlapping agents are chaotic: float32 drifts past 1e-4 within an episode whatever the
+    kernel does, so float32 is checked teacher-forced (one step from the reference's state)."""
+    g = load_golden("spread64")
+    T, B, A = g["actions"].shape
+    env = _env("spread64", B, torch.float32)
+    pos_prev, vel_prev = g["pos0"].copy(), g["vel0"]
+    for t in range(T):
+        env.set_state(pos_prev, vel_prev)
+        obs, rew, done, _ = env.step(torch.as_tensor(g["actions"][t]))
+        pos, vel, _ = env.get_state()
+        assert _close(pos[:, :A], g["pos"][t], 1e-4, 1e-4), (t, np.abs(pos[:, :A] - g["pos"][t]).max())
+        assert _close(vel, g["vel"][t], 1e-4, 2e-4), (t, np.abs(vel - g["vel"][t]).max())
+        pos_prev = pos_prev.copy()
+        pos_prev[:, :A] = g["pos"][t]
+        vel_prev = g["vel"][t]
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_spread64_rollout_equals_repeated_step(dtype):
+    dt = getattr(torch, dtype)
+    g = load_golden("spread64")
+    a = torch.as_tensor(g["actions"][:5]).to("cuda:0")
+    e1, e2 = _env("spread64", 2, dt), _env("spread64", 2, dt)
+    e1.set_state(g["pos0"], g["vel0"])
+    e2.set_state(g["pos0"], g["vel0"])
+    out = e2.rollout(a)
+    for t in range(5):
+        obs, rew, done, (ii, ff) = e1.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t])
+        assert torch.equal(ii, out["info_i"][t]) and torch.equal(ff, out["info_f"][t])
+    assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.vel, e2.vel)
+
+
+@pytest.mark.parametrize("A,L", [(2, 1), (5, 7), (9, 4), (33, 20)])
+def test_spread_other_sizes_against_oracle(A, L):
+    """simple_spread at sizes other than the lane-per-world 3/3 runs on the wave-per-world kernel."""
+    import mpe_hip
+    spec = orc.spec_spread(A, L)
+    B = 50
+    rng = np.random.RandomState(A * 100 + L)
+    pos = rng.uniform(-1, 1, (B, A + L, 2))
+    vel = rng.uniform(-0.5, 0.5, (B, A, 2))
+    env = mpe_hip.BatchedEnv("simple_spread", B, dtype=torch.float64, info=True, n_agents=A, n_landmarks=L)
+    env.set_state(pos, vel)
+    assert _close(env.observe().cpu().numpy(), np.concatenate(orc.observe(spec, pos, vel, None), 1), 1e-6, 1e-12)
+    for t in range(10):
+        act = rng.randint(0, 5, (B, A))
+        obs, rew, done, (ii, ff) = env.step(torch.as_tensor(act, dtype=torch.int32))
+        pos, vel, comm, o_obs, o_rew, _ = orc.env_step(spec, pos, vel, act)
+    g_pos, g_vel, _ = env.get_state()
+    assert _close(g_pos, pos, 1e-9, 1e-12) and _close(g_vel, vel, 1e-9, 1e-12)
+    assert _close(obs.cpu().numpy(), np.concatenate(o_obs, 1), 1e-6, 1e-12)
+    assert _close(rew.cpu().numpy(), o_rew, 1e-9, 1e-12)
+    inf = orc.info(spec, pos)
+    assert np.array_equal(ii.cpu().numpy()[:, :A], inf["collisions"]) and np.array_equal(ii.cpu().numpy()[:, A], inf["occupied"])
+
+
+@pytest.mark.parametrize("scn", ["simple_tag", "simple_world_comm"])
+def test_world_step_physics_only_matches_oracle(scn):
+    """mpe_world_step: World.step with forces and comm actions given directly, checked against the
+    oracle's world_step on the simple_tag / simple_world_comm worlds (speed clamp, obstacles,
+    one speaking agent)."""
+    import mpe_hip
+    spec = orc.make_spec(scn)
+    ps = mpe_hip.make_spec(scn)
+    phys = mpe_hip.physics_spec(ps.n_agents, ps.n_landmarks, ps.dim_c, ps.size, ps.mass, ps.collide, ps.sensitivity,
+                                ps.max_speed, ps.silent)
+    B = 300
+    rng = np.random.RandomState(11)
+    pos = np.concatenate([rng.uniform(-1, 1, (B, spec.A, 2)), rng.uniform(-0.9, 0.9, (B, spec.L, 2))], axis=1)
+    vel = rng.uniform(-1, 1, (B, spec.A, 2))
+    env = mpe_hip.BatchedEnv(phys, B, dtype=torch.float64)
+    env.set_state(pos, vel)
+    for t in range(10):
+        act = rng.randint(0, 5, (B, spec.n_act))
+        if scn == "simple_world_comm":
+            act[:, 1] = rng.randint(0, 4, B)
+        u, c = orc.decode_actions(spec, act)
+        speakers = [i for i in range(spec.A) if not spec.silent[i]]
+        env.world_step(u.reshape(B, -1), c[:, speakers, :].reshape(B, -1) if speakers else None)
+        pos, vel, comm = orc.world_step(spec, pos, vel, u, c)
+    g_pos, g_vel, g_comm = env.get_state()
+    assert _close(g_pos, pos, 1e-9, 1e-12), np.abs(g_pos - pos).max()
+    assert _close(g_vel, vel, 1e-9, 1e-12)
+    if speakers:
+        assert np.array_equal(g_comm, comm[:, speakers, :].reshape(B, -1))

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Profile bench.py with rocprofv3 on the GPU box and summarise the result.
+
+Three separate runs (counters are never combined with tracing, and FETCH_SIZE / WRITE_SIZE do not
+fit one pass):
+  1. rocprofv3 --kernel-trace --stats      -> per-kernel call counts and average durations
+  2. rocprofv3 --pmc FETCH_SIZE            -> bytes read from beyond L2, per dispatch
+  3. rocprofv3 --pmc WRITE_SIZE            -> bytes written beyond L2, per dispatch
+
+Writes into <out>/ :  kernel_stats.csv (copy of pass 1's table), bench.json (the line bench.py
+printed under pass 1) and traffic.json, keyed like bench.py's lookup
+("<scenario>_<dtype>_B<envs>_<mode>"), holding HBM bytes per launch of the dominant kernel:
+    hbm_bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024
+FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-byte read requests
+at 64 bytes, i.e. half the bytes of a coalesced streaming read, hence the factor 2 (checked here
+against the known byte count of this kernel's reads, see "fetch_check" in the output).
+
+Usage (on the GPU box, through gpurun):
+    python3 tools/collect_profiles.py --out gpurun_out/prof_r01 [-- extra bench.py args]
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, log, limit):
+    with open(log, "w") as f:
+        try:
+            return subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, timeout=limit, cwd=ROOT).returncode
+        except subprocess.TimeoutExpired:
+            return 124
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/prof")
+    ap.add_argument("--scenario", default="simple_spread")
+    ap.add_argument("--envs", type=int, default=65536)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--mode", default="rollout")
+    ap.add_argument("--kernel", default=None, help="substring of the dominant kernel's name")
+    args, extra = ap.parse_known_args()
+    out = os.path.join(ROOT, args.out) if not os.path.isabs(args.out) else args.out
+    os.makedirs(out, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    os.environ.update(env)
+    bench = ["python3", "bench.py", "--no-cpu-baseline", "--scenario", args.scenario, "--envs", str(args.envs),
+             "--dtype", args.dtype, "--mode", args.mode] + [a for a in extra if a != "--"]
+    mode_tag = {"rollout": ", 1>(", "step": ", 0>(", "graph": ", 0>("}[args.mode]   # MODE template argument
+    kern = args.kernel or "small_kernel<%s" % ("float" if args.dtype == "f32" else "double")
+
+    rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(out, "stats"), "--"] + bench,
+             os.path.join(out, "stats.log"), 400)
+    print("stats pass rc", rc)
+    if rc != 0:
+        sys.exit(rc)
+    for fn in glob.glob(os.path.join(out, "stats", "**", "*_kernel_stats.csv"), recursive=True):
+        shutil.copy(fn, os.path.join(out, "kernel_stats.csv"))
+    for line in open(os.path.join(out, "stats.log")):
+        if line.startswith("{") and '"metric"' in line:
+            open(os.path.join(out, "bench.json"), "w").write(line)
+    short = bench + ["--no-step-mode", "--steps", "250", "--warmup", "25"]
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, counter.lower())
+        rc = run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + short, os.path.join(out, counter.lower() + ".log"), 200)
+        print(counter, "pass rc", rc)
+        if rc != 0:
+            sys.exit(rc)
+        # the dominant kernel: small_kernel<T, Cfg, CLAMP, MODE> with MODE 1 = rollout, 0 = step
+        vals = []
+        for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(fn)):
+                if r["Counter_Name"] == counter and kern in r["Kernel_Name"] and mode_tag in r["Kernel_Name"]:
+                    vals.append(float(r["Counter_Value"]))
+        res[counter] = (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+    fetch_kib, n_f = res["FETCH_SIZE"]
+    write_kib, n_w = res["WRITE_SIZE"]
+    key = "%s_%s_B%d_%s" % (args.scenario, args.dtype, args.envs, args.mode)
+    traffic = {key: {
+        "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib, "dispatches": [n_f, n_w],
+        "hbm_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024 if fetch_kib is not None and write_kib is not None else None,
+        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B); WRITE_SIZE as reported; both KiB",
+    }}
+    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic))
+
+
+if __name__ == "__main__":
+    main()
