@@ -136,10 +136,11 @@ int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void
                 void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps,
                 mpe_stream_t stream);
 
-/* The per-agent observation callbacks on the current state (what MultiAgentEnv.reset returns,
- * environment.py:122-127) without stepping. */
-int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs,
-                mpe_stream_t stream);
+/* The scenario callbacks on the current state, without stepping: observation for every agent
+ * (what MultiAgentEnv.reset returns, environment.py:122-127) and, when rew is not NULL, also
+ * reward (environment.py:149-152) and benchmark_data (info_i / info_f, NULL to skip). */
+int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs, void* rew,
+                int32_t* info_i, void* info_f, mpe_stream_t stream);
 
 /*
  * Scenario.reset_world (simple_spread.py:40-56, simple_tag.py:39-54, simple_world_comm.py:88-113)

@@ -222,8 +222,10 @@ int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void
     return run(h, 1, a, stream, "mpe_rollout");
 }
 
-int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs, mpe_stream_t stream) {
-    const StepArgs a{nullptr, (void*)pos, (void*)vel, (void*)comm, obs, nullptr, nullptr, nullptr, nullptr, 1};
+int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs, void* rew, int32_t* info_i,
+                void* info_f, mpe_stream_t stream) {
+    if (h && !rew && (info_i || info_f)) return fail(h, MPE_ERR_INVALID, "mpe_observe: info_i / info_f require rew");
+    const StepArgs a{nullptr, (void*)pos, (void*)vel, (void*)comm, obs, rew, nullptr, info_i, info_f, 1};
     return run(h, 2, a, stream, "mpe_observe");
 }
 

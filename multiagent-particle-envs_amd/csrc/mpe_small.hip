@@ -158,15 +158,16 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
         }
 
         // ---- scenario callbacks into the wave's LDS tiles ----
+        const bool want_score = (MODE != MODE_OBSERVE) || (rew_g != nullptr);   // observe: rewards on request
         Cfg::template observe<T>(pos, vel, comm, p, ObsTile::row(tile_obs, lane));
-        if (MODE != MODE_OBSERVE)
+        if (want_score)
             Cfg::template score<T>(pos, p, RewTile::row(tile_rew, lane), want_info, IiTile::row(tile_ii, lane), IfTile::row(tile_if, lane));
         __syncthreads();
         const long long row0 = (long long)t * B + env0;
         ObsTile::flush(tile_obs, obs_g + row0 * OT, lane, nvalid, full);
-        if (MODE != MODE_OBSERVE) {
+        if (want_score) {
             RewTile::flush(tile_rew, rew_g + row0 * A, lane, nvalid, full);
-            if (valid) done_g[row0 + lane] = 0;
+            if (MODE != MODE_OBSERVE && valid) done_g[row0 + lane] = 0;
             if (want_info) {
                 IiTile::flush(tile_ii, info_i_g + row0 * NI, lane, nvalid, full);
                 if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::flush(tile_if, info_f_g + row0 * NF, lane, nvalid, full);

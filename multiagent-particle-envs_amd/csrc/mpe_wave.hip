@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void wave_kernel(const WaveParams<T> p, const i
                 obs_env[2 * q] = spread_round<T>(o.x);
                 obs_env[2 * q + 1] = spread_round<T>(o.y);
             }
-            if (MODE != WMODE_OBSERVE) {
+            if (MODE != WMODE_OBSERVE || rew_g != nullptr) {
                 // ---- reward() :83-108 and benchmark_data() :58-74 ----
                 if (lane < L) {
                     const V2<T> pl = P[A + lane];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void wave_kernel(const WaveParams<T> p, const i
                     }
                 }
                 if (lane == 0) {
-                    done_g[row] = 0;
+                    if (MODE != WMODE_OBSERVE) done_g[row] = 0;
                     if (want_info) {
                         info_i_g[row * (A + 1) + A] = occupied;
                         if (info_f_g) info_f_g[row * (A + 1)] = min_dists;

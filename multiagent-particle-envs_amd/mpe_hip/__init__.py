@@ -2,3 +2,6 @@
 from ._lib import MpeError  # noqa: F401
 from .spec import WorldSpec, make_spec, physics_spec, spread_spec, tag_spec, world_comm_spec  # noqa: F401
 from .batch import BatchedEnv  # noqa: F401
+from .world import Action, Agent, AgentState, Entity, EntityState, Landmark, Wall, World  # noqa: F401
+from .scenario import BaseScenario, HipScenario  # noqa: F401
+from .env import MultiAgentEnv, make_env  # noqa: F401

@@ -84,10 +84,12 @@ class BatchedEnv:
         """Per-agent observation views ``[B, obs_dim[i]]`` (the reference's obs_n list)."""
         return [self.obs[:, o:o + d] for o, d in zip(self.obs_offsets, self.obs_dims)]
 
-    def observe(self):
-        """Scenario.observation for every agent of every env on the current state."""
+    def observe(self, score=False):
+        """Scenario.observation for every agent of every env on the current state; with ``score``
+        also Scenario.reward (into ``rew``) and benchmark_data (into ``info_i`` / ``info_f``)."""
         p = self._p
-        _lib.check(self._h, self._lib.mpe_observe(self._h, p["pos"], p["vel"], p["comm"], p["obs"], self._stream()))
+        _lib.check(self._h, self._lib.mpe_observe(self._h, p["pos"], p["vel"], p["comm"], p["obs"], p["rew"] if score else None,
+                                                  p["info_i"] if score else None, p["info_f"] if score else None, self._stream()))
         return self.obs
 
     def reset(self, seed=0, mask=None, observe=True):

@@ -1,0 +1,94 @@
+"""Scenario plugin contract (multiagent/scenario.py:4-10, README.md:33-44) and the base class of
+the built-in scenarios whose callbacks are evaluated by the HIP kernels."""
+import numpy as np
+
+from . import _lib
+from .spec import WorldSpec
+
+
+class BaseScenario:
+    """A scenario supplies ``make_world()`` and ``reset_world(world[, np_random])`` plus the
+    callbacks ``reward(agent, world)``, ``observation(agent, world)`` and optionally
+    ``benchmark_data(agent, world)``, ``done(agent, world)``, ``post_step(world, np_random)``."""
+
+    def make_world(self):
+        raise NotImplementedError()
+
+    def reset_world(self, world, np_random=None):
+        raise NotImplementedError()
+
+
+def spec_from_world(world, scenario_id, name):
+    """WorldSpec of a World object's current static properties."""
+    ents = world.entities
+    ag = world.agents
+    return WorldSpec(scenario_id, len(ag), len(world.landmarks), world.dim_c,
+                     size=np.array([e.size for e in ents], float), mass=np.array([e.mass for e in ents], float),
+                     movable=np.array([bool(e.movable) for e in ents]), collide=np.array([bool(e.collide) for e in ents]),
+                     sensitivity=np.array([a.accel if a.accel is not None else 5.0 for a in ag], float),
+                     max_speed=np.array([a.max_speed if a.max_speed is not None else np.inf for a in ag], float),
+                     silent=np.array([bool(a.silent) for a in ag]),
+                     adversary=np.array([bool(getattr(a, "adversary", False)) for a in ag]),
+                     leader=np.array([bool(getattr(a, "leader", False)) for a in ag]),
+                     dt=world.dt, damping=world.damping, contact_force=world.contact_force,
+                     contact_margin=world.contact_margin, name=name)
+
+
+class HipScenario(BaseScenario):
+    """Built-in scenario: ``observation`` / ``reward`` / ``benchmark_data`` of all agents are
+    computed together by one ``mpe_observe`` launch on a one-world float64 batch and cached until
+    the world's state changes, so the per-agent callbacks of ``MultiAgentEnv`` cost one launch."""
+
+    scenario_id = _lib.SCN_NONE
+    hip_name = ""
+    obs_dtype = np.float64
+
+    def __init__(self):
+        self._env = None        # (signature, BatchedEnv)
+        self._cache = None      # (state key, obs [obs_total], rew [A], info_i, info_f)
+
+    # -- device plumbing ------------------------------------------------
+    def fused_env(self, world):
+        from . import BatchedEnv
+        import torch
+        sig = world._signature() + (tuple(bool(getattr(a, "adversary", False)) for a in world.agents),)
+        if self._env is None or self._env[0] != sig:
+            spec = spec_from_world(world, self.scenario_id, self.hip_name)
+            self._env = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=world.device, info=True))
+            self._cache = None
+        return self._env[1]
+
+    @staticmethod
+    def _key(pos, vel, comm):
+        return pos.tobytes() + vel.tobytes() + (comm.tobytes() if comm is not None else b"")
+
+    def store(self, world, env):
+        """Cache the callbacks' outputs that ``env`` holds for the world's current state."""
+        pos, vel, comm = world.pack_state()
+        self._cache = (self._key(pos, vel, comm), env.obs[0].cpu().numpy(), env.rew[0].cpu().numpy(),
+                       env.info_i[0].cpu().numpy(), env.info_f[0].cpu().numpy() if env.info_f is not None else None)
+
+    def evaluate(self, world):
+        pos, vel, comm = world.pack_state()
+        key = self._key(pos, vel, comm)
+        if self._cache is None or self._cache[0] != key:
+            env = self.fused_env(world)
+            env.set_state(pos, vel, comm)
+            env.observe(score=True)
+            self._cache = (key, env.obs[0].cpu().numpy(), env.rew[0].cpu().numpy(), env.info_i[0].cpu().numpy(),
+                           env.info_f[0].cpu().numpy() if env.info_f is not None else None)
+        return self._cache
+
+    # -- the plugin callbacks --------------------------------------------
+    def observation(self, agent, world):
+        _, obs, _, _, _ = self.evaluate(world)
+        env = self.fused_env(world)
+        i = world.agents.index(agent)
+        o, d = env.obs_offsets[i], env.obs_dims[i]
+        return obs[o:o + d].astype(self.obs_dtype)
+
+    def reward(self, agent, world):
+        return float(self.evaluate(world)[2][world.agents.index(agent)])
+
+    def benchmark_data(self, agent, world):
+        return int(self.evaluate(world)[3][world.agents.index(agent)])

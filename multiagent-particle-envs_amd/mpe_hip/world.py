@@ -1,0 +1,190 @@
+"""Single-world object model with the reference's attribute names, stepped on the GPU.
+
+These classes keep the data model of the reference's ``multiagent/core.py`` (``World`` with
+``agents`` / ``landmarks`` lists of entities carrying ``state.p_pos``, ``state.p_vel``, ``state.c``,
+``action.u``, ``action.c`` and the static properties ``size``, ``movable``, ``collide``, ``mass``,
+``accel``, ``max_speed``, ``silent`` ...) so that existing ``Scenario`` plugins keep working, but
+``World.step()`` does no arithmetic in Python: it packs the entities into a one-world batch, runs
+the ``mpe_world_step`` HIP kernel (action force, pairwise contact force, damped integration with
+speed clamp, comm state) and unpacks the result.  There is no CPU physics path.
+"""
+import numpy as np
+
+__all__ = ["EntityState", "AgentState", "Action", "Entity", "Landmark", "Agent", "Wall", "World"]
+
+
+class EntityState:
+    """Physical state (multiagent/core.py:4-9)."""
+
+    def __init__(self):
+        self.p_pos = None
+        self.p_vel = None
+
+
+class AgentState(EntityState):
+    """Adds the communication utterance ``c`` (multiagent/core.py:12-16)."""
+
+    def __init__(self):
+        super().__init__()
+        self.c = None
+
+
+class Action:
+    """Physical action ``u`` and communication action ``c`` (multiagent/core.py:19-24)."""
+
+    def __init__(self):
+        self.u = None
+        self.c = None
+
+
+class Wall:
+    """Kept for attribute compatibility (multiagent/core.py:26-42).  Wall contact is not
+    simulated: a world with walls refuses to step."""
+
+    def __init__(self, orient="H", axis_pos=0.0, endpoints=(-1, 1), width=0.1, hard=True):
+        self.orient, self.axis_pos, self.endpoints = orient, axis_pos, np.array(endpoints)
+        self.width, self.hard, self.visible = width, hard, False
+        self.color = np.zeros(3, dtype=np.float32)
+
+
+class Entity:
+    """Defaults of multiagent/core.py:45-71."""
+
+    def __init__(self):
+        self.name = ""
+        self.size = 0.050
+        self.movable = False
+        self.collide = True
+        self.density = 25.0
+        self.color = None
+        self.visible = True
+        self.max_speed = None
+        self.accel = None
+        self.state = EntityState()
+        self.initial_mass = 1.0
+
+    @property
+    def mass(self):
+        return self.initial_mass
+
+
+class Landmark(Entity):
+    pass
+
+
+class Agent(Entity):
+    """Defaults of multiagent/core.py:79-101."""
+
+    def __init__(self):
+        super().__init__()
+        self.movable = True
+        self.silent = False
+        self.blind = False
+        self.ghost = False
+        self.u_noise = None
+        self.c_noise = None
+        self.u_range = 1.0
+        self.state = AgentState()
+        self.action = Action()
+        self.action_callback = None
+
+
+class World:
+    """World constants of multiagent/core.py:104-124; ``step()`` runs on the GPU."""
+
+    def __init__(self):
+        self.agents = []
+        self.landmarks = []
+        self.walls = []
+        self.dim_c = 0
+        self.dim_p = 2
+        self.dim_color = 3
+        self.dt = 0.1
+        self.t = 0
+        self.damping = 0.25
+        self.contact_force = 1e2
+        self.contact_margin = 1e-3
+        self.device = "cuda:0"
+        self._phys = None          # (signature, BatchedEnv) of the physics-only handle
+
+    @property
+    def entities(self):
+        return self.agents + self.landmarks
+
+    @property
+    def policy_agents(self):
+        return [a for a in self.agents if a.action_callback is None]
+
+    @property
+    def scripted_agents(self):
+        return [a for a in self.agents if a.action_callback is not None]
+
+    # ------------------------------------------------------------------
+    def _signature(self):
+        ents = self.entities
+        return (len(self.agents), len(self.landmarks), self.dim_c, self.dt, self.damping, self.contact_force, self.contact_margin,
+                tuple((e.size, e.mass, bool(e.movable), bool(e.collide)) for e in ents),
+                tuple((a.max_speed, bool(a.silent)) for a in self.agents), str(self.device))
+
+    def _physics_env(self):
+        """One-world physics handle matching the entities' current static properties."""
+        from . import BatchedEnv, physics_spec
+        import torch
+        sig = self._signature()
+        if self._phys is None or self._phys[0] != sig:
+            A = len(self.agents)
+            ents = self.entities
+            if self.walls:
+                raise NotImplementedError("worlds with walls are not simulated by the HIP kernels")
+            spec = physics_spec(A, len(self.landmarks), self.dim_c,
+                                size=[e.size for e in ents], mass=[e.mass for e in ents], collide=[e.collide for e in ents],
+                                sensitivity=[a.accel if a.accel is not None else 5.0 for a in self.agents],
+                                max_speed=[a.max_speed if a.max_speed is not None else np.inf for a in self.agents],
+                                silent=[a.silent for a in self.agents],
+                                dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin)
+            spec.movable = np.array([bool(e.movable) for e in ents])     # mpe_create refuses immovable agents / movable landmarks
+            self._phys = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=self.device))
+        return self._phys[1]
+
+    def pack_state(self):
+        """(pos [1, E, 2], vel [1, A, 2], comm [1, S*dim_c]) float64 from the entity objects."""
+        pos = np.array([e.state.p_pos for e in self.entities], dtype=np.float64)[None]
+        vel = np.array([a.state.p_vel for a in self.agents], dtype=np.float64)[None]
+        comm = [np.asarray(a.state.c, dtype=np.float64) if a.state.c is not None else np.zeros(self.dim_c)
+                for a in self.agents if not a.silent]
+        return pos, vel, (np.concatenate(comm)[None] if comm else None)
+
+    def unpack_state(self, pos, vel, comm):
+        A = len(self.agents)
+        for i, a in enumerate(self.agents):
+            a.state.p_pos = np.array(pos[0, i])
+            a.state.p_vel = np.array(vel[0, i])
+        k = 0
+        for a in self.agents:
+            if a.silent:
+                a.state.c = np.zeros(self.dim_c, dtype=np.float32)      # multiagent/core.py:208-209
+            else:
+                a.state.c = np.array(comm[0, k * self.dim_c:(k + 1) * self.dim_c])
+                k += 1
+
+    def step(self):
+        """World.step (multiagent/core.py:142-158): scripted agents act, then the GPU integrates."""
+        self.t += 1
+        for agent in self.scripted_agents:
+            agent.action = agent.action_callback(agent, self)
+        env = self._physics_env()
+        A = len(self.agents)
+        u = np.zeros((1, 2 * A))
+        c_rows = []
+        for i, a in enumerate(self.agents):
+            # motor / comm noise is drawn on the host exactly where the reference draws it
+            # (multiagent/core.py:165,211); no in-scope scenario sets it
+            un = np.random.randn(*a.action.u.shape) * a.u_noise if a.u_noise else 0.0
+            u[0, 2 * i:2 * i + 2] = np.asarray(a.action.u, dtype=np.float64) + un
+            if not a.silent:
+                cn = np.random.randn(*a.action.c.shape) * a.c_noise if a.c_noise else 0.0
+                c_rows.append(np.asarray(a.action.c, dtype=np.float64) + cn)
+        pos, vel, comm = self.pack_state()
+        env.set_state(pos, vel, comm)
+        env.world_step(u, np.concatenate(c_rows)[None] if c_rows else None)
+        self.unpack_state(*env.get_state())

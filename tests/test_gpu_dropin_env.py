@@ -1,0 +1,156 @@
+"""The drop-in single-world API (MultiAgentEnv / make_env / Scenario plugins) on the GPU path,
+against the reference's own outputs (golden fixtures and known answers)."""
+import numpy as np
+import pytest
+
+import mpe_oracle as orc
+from conftest import load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-9, atol=1e-12):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def test_make_env_simple_spread_known_answer():
+    """env.seed(1); env.reset(); 25 steps of actions (t+i) % 5 -- the same calls made on the
+    reference when tests/golden/kat.npz was captured (numpy RandomState(1) reset draws)."""
+    from make_env import make_env
+    k = load_golden("kat")
+    env = make_env("simple_spread", benchmark=True)
+    assert env.n == 3 and [s.n for s in env.action_space] == [5, 5, 5]
+    assert [s.shape for s in env.observation_space] == [(14,)] * 3
+    assert np.array_equal(env.world.comm_matrix, k["spread_comm_matrix"])
+    env.seed(1)
+    obs_n = env.reset()
+    assert np.array_equal(np.array([e.state.p_pos for e in env.world.entities]), k["kat1_pos0"])
+    assert obs_n[0].dtype == np.float32 and obs_n[0].shape == (14,)
+    ret0 = 0.0
+    for t in range(25):
+        obs_n, rew_n, done, info = env.step([(t + i) % 5 for i in range(3)])
+        ret0 += rew_n[0]
+        assert done is False and set(info) == {"n", "r0", "r1", "r2"}
+    assert _close([a.state.p_pos for a in env.world.agents], k["kat1_pos"])
+    assert _close([a.state.p_vel for a in env.world.agents], k["kat1_vel"])
+    assert _close(rew_n, k["kat1_rew"])
+    assert _close(ret0, k["kat1_return0"])
+    assert _close(np.concatenate(obs_n), k["kat1_obs"], 1e-6, 1e-7)
+    r, coll, md, occ = info["n"][0]
+    assert _close([r, md], k["kat1_info0"][[0, 2]]) and [coll, occ] == list(k["kat1_info0"][[1, 3]])
+
+
+@pytest.mark.parametrize("name,case", [("simple_tag", "tag"), ("simple_world_comm", "world_comm")])
+def test_builtin_scenarios_replay_reference_episode(name, case):
+    from make_env import make_env
+    g = load_golden(case)
+    env = make_env(name, benchmark=True)
+    env.seed(0)
+    env.reset()
+    A = env.n
+    dims = list(g["obs_dims"])
+    assert [s.shape[0] for s in env.observation_space] == dims
+    for b in (0, 9, 17, 30):
+        for i, e in enumerate(env.world.entities):
+            e.state.p_pos = g["pos0"][b, i].copy()
+        for i, a in enumerate(env.world.agents):
+            a.state.p_vel = g["vel0"][b, i].copy()
+            a.state.c = np.zeros(env.world.dim_c)
+        for t in range(25):
+            act = g["actions"][t, b]
+            action_n = [(int(act[0]), int(act[1]))] + [int(x) for x in act[2:]] if name == "simple_world_comm" else [int(x) for x in act]
+            obs_n, rew_n, done, info = env.step(action_n)
+            assert _close(np.concatenate(obs_n), g["obs"][t, b]), (b, t)
+            assert _close(rew_n, g["rew"][t, b]), (b, t)
+            assert list(info["n"]) == list(g["collisions"][t, b]) and done is False
+        assert _close([a.state.p_pos for a in env.world.agents], g["pos"][24, b])
+        assert _close([a.state.p_vel for a in env.world.agents], g["vel"][24, b])
+    if name == "simple_world_comm":
+        assert type(env.action_space[0]).__name__ == "Tuple" and env.action_space[1].n == 5
+        assert np.array_equal(env.world.agents[0].state.c, g["comm"][24, 30])
+
+
+class _UserTagScenario:
+    """A scenario written against the plugin contract only (Python callbacks reading
+    agent.state / agent attributes), as a user of the reference would write it: simple_tag's
+    world with a custom reward and observation."""
+
+    def make_world(self):
+        from multiagent.core import World, Agent, Landmark
+        w = World()
+        w.dim_c = 2
+        w.agents = [Agent() for _ in range(4)]
+        for i, a in enumerate(w.agents):
+            a.name, a.collide, a.silent, a.adversary = "agent %d" % i, True, True, i < 3
+            a.size, a.accel, a.max_speed = (0.075, 3.0, 1.0) if a.adversary else (0.05, 4.0, 1.3)
+        w.landmarks = [Landmark() for _ in range(2)]
+        for lm in w.landmarks:
+            lm.collide, lm.movable, lm.size = True, False, 0.2
+        self.reset_world(w)
+        return w
+
+    def reset_world(self, world):
+        rng = np.random.RandomState(5)
+        for a in world.agents:
+            a.state.p_pos, a.state.p_vel, a.state.c = rng.uniform(-1, 1, 2), np.zeros(2), np.zeros(2)
+        for lm in world.landmarks:
+            lm.state.p_pos, lm.state.p_vel = rng.uniform(-0.9, 0.9, 2), np.zeros(2)
+
+    def reward(self, agent, world):
+        return -float(np.sum(np.square(agent.state.p_pos)))
+
+    def observation(self, agent, world):
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos] + [lm.state.p_pos - agent.state.p_pos for lm in world.landmarks])
+
+
+def test_user_scenario_plugin_runs_physics_on_gpu():
+    from multiagent.environment import MultiAgentEnv
+    sc = _UserTagScenario()
+    world = sc.make_world()
+    env = MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation)
+    assert env._scenario is None                          # generic path: kernels for physics, Python callbacks
+    env.seed(0)
+    obs_n = env.reset()
+    assert [o.shape for o in obs_n] == [(8,)] * 4
+    spec = orc.spec_tag()
+    pos = np.array([e.state.p_pos for e in world.entities])[None]
+    vel = np.zeros((1, 4, 2))
+    rng = np.random.RandomState(3)
+    for t in range(25):
+        act = rng.randint(0, 5, 4)
+        obs_n, rew_n, done, info = env.step(list(act))
+        u, c = orc.decode_actions(spec, act[None])
+        pos, vel, _ = orc.world_step(spec, pos, vel, u, c)
+        assert _close([a.state.p_pos for a in world.agents], pos[0, :4]), t
+        assert _close([a.state.p_vel for a in world.agents], vel[0]), t
+        assert _close(rew_n[2], -np.sum(pos[0, 2] ** 2))
+        assert info == {"n": [{}] * 4, "r0": rew_n[0], "r1": rew_n[1], "r2": rew_n[2], "r3": rew_n[3]}
+    assert world.t == 25
+
+
+def test_env_error_behaviour():
+    from make_env import make_env
+    env = make_env("simple_spread")
+    with pytest.raises(AttributeError):
+        env.reset()                                        # the reference also fails before seed()
+    env.seed(3)
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step([0, 1])
+    wc = make_env("simple_world_comm")
+    wc.seed(0)
+    wc.reset()
+    with pytest.raises(ValueError):
+        wc.step([1, 1, 1, 1, 1, 1])                        # the leader needs (move, comm)
+    with pytest.raises(IndexError):
+        wc.step([(1, 7), 1, 1, 1, 1, 1])
+    from mpe_hip import scenarios
+    with pytest.raises(FileNotFoundError):
+        scenarios.load("no_such_scenario.py")
+    env.world.walls.append(object())
+    env2_world = env.world
+    with pytest.raises(NotImplementedError):
+        env2_world._phys = None
+        env2_world.step()
