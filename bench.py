@@ -105,8 +105,10 @@ def main():
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     kw = dict(n_agents=args.agents, n_landmarks=args.landmarks) if args.scenario == "simple_spread" else {}
     env = mpe_hip.BatchedEnv(args.scenario, args.envs, dtype=tdt, device=dev, **kw)
+    from mpe_hip.dist import EpisodeStats, shard_range
     B, A, n_act = args.envs, env.n_agents, env.n_act
-    first_env = rank * B                       # shard [rank*B, (rank+1)*B) of the global env index
+    first_env, last_env = shard_range(world * B, rank, world)    # this rank's slice of the global env index
+    assert last_env - first_env == B
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
@@ -222,11 +224,11 @@ def main():
                      "roofline_frac": b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_env_step": b2 / B}
         pairs[:] = pairs_saved
 
-    # optional statistics all-reduce, outside every timed region: mean last-step reward of agent 0
-    stat = (out["rew"][-1, :, 0] if out is not None else env.rew[:, 0]).double().sum().reshape(1)
-    if world > 1:
-        dist.all_reduce(stat, op=dist.ReduceOp.SUM)
-    mean_rew0 = float(stat.item()) / (world * B)
+    # optional statistics all-reduce (RCCL), outside every timed region: return of agent 0 over the last episode
+    stats = EpisodeStats(dev)
+    stats.add_episode(out["rew"] if out is not None else env.rew)
+    tot = stats.reduce()
+    mean_rew0 = tot["return_agent0"] / max(1.0, tot["episodes"])
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -262,7 +264,7 @@ def main():
                          "launch_ms_hip_events": kern_ms, "launches": launches},
             "cpu_baseline": cpu,
             "step_mode": step_mode,
-            "mean_last_reward_agent0": mean_rew0,
+            "mean_episode_return_agent0": mean_rew0,
         }
         print(json.dumps(line))
     if world > 1:
