@@ -1,0 +1,308 @@
+// Fused step kernels for the small scenarios (simple_spread 3/3, simple_tag, simple_world_comm).
+//
+// One lane owns one world and keeps its whole state in registers: it decodes the int actions,
+// runs World.step (action force, pairwise contact force, integration, comm state) and evaluates
+// the scenario's observation / reward / info callbacks.  State is stored env-minor (SoA), so
+// state loads and stores are coalesced 256-byte rows per wave.  The per-env output rows
+// (observations, rewards, info) are env-major; each wave transposes them through LDS and streams
+// them out as contiguous 16-byte vectors.
+//
+// A workgroup is a single 64-lane wave: the LDS tiles are private to the wave, so the
+// __syncthreads() below are plain LDS waits, not hardware barriers.
+#pragma once
+#include "mpe_scenarios.hpp"
+#include "mpe_launch.hpp"
+
+namespace mpe {
+
+enum { MODE_STEP = 0, MODE_ROLLOUT = 1, MODE_OBSERVE = 2 };
+
+// ---- wave-private LDS tile holding W values for each of the wave's ROWS consecutive envs --------
+// Lane l writes its env's row, then the wave streams the tile to the env-major global array.
+//
+// LINEAR: rows are stored back to back (row stride W), i.e. the tile is a byte image of the wave's
+//   contiguous 64*W-element block of the global array, which goes out as 16-byte vectors with no
+//   index arithmetic.  Row writes then land with lane stride W: fine when W*sizeof(V)/4 is not a
+//   multiple of a large power of two (simple_spread 42, simple_tag 62: 2-way, free for ds_write).
+// PADDED: row stride W|1 (odd) keeps both directions conflict-free for any W (simple_world_comm:
+//   192 values per row would otherwise be a 32-way conflict) at the price of a divide per element.
+template <typename V, int W, bool LINEAR, int ROWS>
+struct Tile {
+    static constexpr int STRIDE = LINEAR ? W : (W | 1);
+    static constexpr int SIZE = ROWS * STRIDE;
+    static constexpr int VEC = 16 / (int)sizeof(V);
+
+    __device__ static __forceinline__ V* row(V* tile, int lane) { return tile + lane * STRIDE; }
+
+    // FULL: all 64 envs valid and gdst 16-byte aligned (fixed per kernel instantiation, so the
+    // fast path is straight-line code and the compiler can count outstanding stores)
+    template <bool FULL>
+    __device__ static __forceinline__ void flush(const V* tile, V* gdst, int lane, int nvalid) {
+        if (LINEAR && FULL) {
+            typedef V VT __attribute__((ext_vector_type(VEC)));
+            static_assert((ROWS * W) % VEC == 0, "tile must be a whole number of 16-byte vectors");
+            constexpr int NV = ROWS * W / VEC, FULL_IT = NV / 64, REM = NV % 64;
+            const VT* src = reinterpret_cast<const VT*>(tile);
+            VT* dst = reinterpret_cast<VT*>(gdst);
+#pragma unroll
+#if defined(MPE_PROBE_NO_STORES)   // diagnostic build: LDS reads kept alive, nothing written
+            for (int it = 0; it < FULL_IT; ++it) { VT v = src[it * 64 + lane]; asm volatile("" :: "v"(v)); }
+            if (REM > 0 && lane < REM) { VT v = src[FULL_IT * 64 + lane]; asm volatile("" :: "v"(v)); }
+            (void)dst;
+#elif defined(MPE_NT_STORES)
+            for (int it = 0; it < FULL_IT; ++it) __builtin_nontemporal_store(src[it * 64 + lane], &dst[it * 64 + lane]);
+            if (REM > 0 && lane < REM) __builtin_nontemporal_store(src[FULL_IT * 64 + lane], &dst[FULL_IT * 64 + lane]);
+#else
+            for (int it = 0; it < FULL_IT; ++it) dst[it * 64 + lane] = src[it * 64 + lane];
+            if (REM > 0 && lane < REM) dst[FULL_IT * 64 + lane] = src[FULL_IT * 64 + lane];
+#endif
+        } else {
+            const int n = nvalid * W;
+#pragma unroll
+            for (int it = 0; it < (ROWS * W + 63) / 64; ++it) {
+                const int g = it * 64 + lane;
+                if (LINEAR) {
+                    if (g < n) gdst[g] = tile[g];
+                } else {
+                    const int r = g / W;
+                    if (g < n) gdst[g] = tile[r * STRIDE + (g - r * W)];
+                }
+            }
+        }
+    }
+};
+
+// EPW: envs per wave (tile rows); 64 uses every lane.
+// FULL: every wave of the launch owns EPW valid envs and all output blocks are 16-byte aligned.
+// INFO: info_i / info_f are written.  env_begin / env_end: the env range this launch covers.
+template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW>
+__global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const long long env_begin,
+                                                   const long long env_end,
+                                                   const int* __restrict__ actions, T* __restrict__ pos_g,
+                                                   T* __restrict__ vel_g, T* __restrict__ comm_g,
+                                                   T* __restrict__ obs_g, T* __restrict__ rew_g,
+                                                   uint8_t* __restrict__ done_g, int* __restrict__ info_i_g,
+                                                   T* __restrict__ info_f_g, int n_steps) {
+    constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
+    constexpr int NI = Cfg::NI, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C;
+    constexpr bool LIN = ((OT * (int)sizeof(T) / 4) % 16) != 0;
+    using ObsTile = Tile<T, OT, LIN, EPW>;
+    using RewTile = Tile<T, A, true, EPW>;
+    using IiTile = Tile<int, NI, true, EPW>;
+    using IfTile = Tile<T, NF, true, EPW>;
+    __shared__ __attribute__((aligned(16))) T tile_obs[ObsTile::SIZE];
+    __shared__ __attribute__((aligned(16))) T tile_rew[RewTile::SIZE];
+    __shared__ __attribute__((aligned(16))) int tile_ii[IiTile::SIZE];
+    __shared__ __attribute__((aligned(16))) T tile_if[IfTile::SIZE];
+
+    const int lane = threadIdx.x;
+    const long long B = p.n_envs;
+    const long long env0 = env_begin + (long long)blockIdx.x * EPW;
+    const long long left = env_end - env0;
+    const int nvalid = FULL ? EPW : (left < EPW ? (int)left : EPW);
+    const bool valid = lane < nvalid;
+    const int tile_lane = (EPW == 64 || lane < EPW) ? lane : 0;   // lanes beyond the tile write row 0 (masked below)
+    const long long b = valid ? env0 + lane : env0;   // idle tail lanes shadow the wave's first env
+
+    V2<T> pos[E];
+    V2<T> vel[A];
+    T comm[DC > 0 ? DC : 1];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        pos[e].x = pos_g[(long long)(2 * e) * B + b];
+        pos[e].y = pos_g[(long long)(2 * e + 1) * B + b];
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        vel[i].x = vel_g[(long long)(2 * i) * B + b];
+        vel[i].y = vel_g[(long long)(2 * i + 1) * B + b];
+    }
+    if (DC > 0) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c) comm[c] = (MODE == MODE_OBSERVE) ? comm_g[(long long)c * B + b] : T(0);
+    }
+    constexpr bool want_info = INFO;
+
+    // Actions are fetched a chunk of CH steps at a time and packed 3 bits each into a 128-bit shift
+    // register, so the step loop itself issues no loads: memory operations retire in issue order,
+    // and a load issued between two steps' store bursts could only be consumed after every older
+    // store had drained.  Move ints outside 0..7 are no-ops like any value outside 1..4
+    // (environment.py:178-181); a comm int outside 0..7 selects no word.
+    constexpr int ABITS = 3 * NA;
+    constexpr int CH = (MODE == MODE_ROLLOUT) ? (128 / ABITS) : 1;
+    static_assert(ABITS <= 64, "one step's actions must fit 64 bits");
+
+    for (int t0 = 0; t0 < n_steps; t0 += CH) {
+      unsigned __int128 packed = 0;
+      if (MODE != MODE_OBSERVE) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const long long tt = (t0 + k < n_steps) ? t0 + k : n_steps - 1;
+            int col = 0;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const unsigned mv = (unsigned)actions[(tt * B + b) * NA + col];
+                packed |= (unsigned __int128)(mv > 7u ? 0u : mv) << (k * ABITS + 3 * col);
+                ++col;
+                if (Cfg::speaks(i)) {
+                    const unsigned wd = (unsigned)actions[(tt * B + b) * NA + col];
+                    packed |= (unsigned __int128)(wd > 7u ? 7u : wd) << (k * ABITS + 3 * col);
+                    ++col;
+                }
+            }
+        }
+      }
+      const int nc = (n_steps - t0 < CH) ? n_steps - t0 : CH;
+      for (int kc = 0; kc < nc; ++kc) {
+        const int t = t0 + kc;
+        if (MODE != MODE_OBSERVE) {
+            const unsigned long long cur = (unsigned long long)packed;
+            packed >>= ABITS;
+            int act[NA];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) act[j] = (int)((cur >> (3 * j)) & 7u);
+            // ---- MultiAgentEnv._set_action: int actions -> forces and comm one-hot ----
+            V2<T> force[A];
+            int col = 0;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                force[i] = decode_move<T>(act[col++], p.sens[i]);     // apply_action_force: u + 0
+                if (Cfg::speaks(i)) {
+                    const int word = act[col++];
+#pragma unroll
+                    for (int c = 0; c < DC; ++c) comm[c] = (word == c) ? T(1) : T(0);   // update_agent_state
+                }
+            }
+            // ---- World.apply_environment_force: pairs in the reference's (a, b) order ----
+#pragma unroll
+            for (int a = 0; a < E; ++a) {
+#pragma unroll
+                for (int c = a + 1; c < E; ++c) {
+                    if (!Cfg::collides(a) || !Cfg::collides(c)) continue;
+                    if (a >= A && c >= A) continue;   // neither entity moves
+                    const V2<T> f = contact_force<T>(pos[a], pos[c], p.size[a] + p.size[c], p.contact_force, p.contact_margin);
+                    if (a < A) { force[a].x = f.x + force[a].x; force[a].y = f.y + force[a].y; }
+                    if (c < A) { force[c].x = -f.x + force[c].x; force[c].y = -f.y + force[c].y; }
+                }
+            }
+            // ---- World.integrate_state ----
+#pragma unroll
+            for (int i = 0; i < A; ++i)
+                integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[i], p.max_speed[i], p.one_minus_damping, p.dt);
+        }
+
+        // ---- scenario callbacks into the wave's LDS tiles ----
+        const bool want_score = (MODE != MODE_OBSERVE) || (rew_g != nullptr);   // observe: rewards on request
+        if (EPW == 64 || lane < EPW) {
+            Cfg::template observe<T>(pos, vel, comm, p, ObsTile::row(tile_obs, tile_lane));
+            if (want_score)
+                Cfg::template score<T>(pos, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
+        }
+        __syncthreads();
+        const long long row0 = (long long)t * B + env0;
+        ObsTile::template flush<FULL>(tile_obs, obs_g + row0 * OT, lane, nvalid);
+        if (want_score) {
+            RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane, nvalid);
+#ifndef MPE_NO_DONE
+            if (MODE != MODE_OBSERVE && valid) done_g[row0 + lane] = 0;
+#endif
+            if (want_info) {
+                IiTile::template flush<FULL>(tile_ii, info_i_g + row0 * NI, lane, nvalid);
+                if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::template flush<FULL>(tile_if, info_f_g + row0 * NF, lane, nvalid);
+            }
+        }
+        if (MODE == MODE_ROLLOUT) __syncthreads();   // tiles are rewritten by the next step
+      }
+    }
+
+    if (MODE != MODE_OBSERVE && valid) {
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            pos_g[(long long)(2 * i) * B + b] = pos[i].x;
+            pos_g[(long long)(2 * i + 1) * B + b] = pos[i].y;
+            vel_g[(long long)(2 * i) * B + b] = vel[i].x;
+            vel_g[(long long)(2 * i + 1) * B + b] = vel[i].y;
+        }
+        if (DC > 0) {
+#pragma unroll
+            for (int c = 0; c < DC; ++c) comm_g[(long long)c * B + b] = comm[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, class Cfg>
+static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n_envs) {
+    SmallParams<T, Cfg::E, Cfg::A> p;
+    for (int e = 0; e < Cfg::E; ++e) p.size[e] = (T)s.size[e];
+    for (int i = 0; i < Cfg::A; ++i) {
+        p.mass[i] = (T)s.mass[i];
+        p.sens[i] = (T)s.sens[i];
+        p.max_speed[i] = (T)s.max_speed[i];
+    }
+    p.dt = (T)s.dt;
+    p.one_minus_damping = (T)(1 - s.damping);   // reference evaluates (1 - damping) in float64 first
+    p.contact_force = (T)s.contact_force;
+    p.contact_margin = (T)s.contact_margin;
+    p.n_envs = n_envs;
+    return p;
+}
+
+template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW>
+static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_begin, long long env_end, const StepArgs& a, hipStream_t st) {
+    if (env_end <= env_begin) return;
+    const dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
+    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>), grid, block, 0, st, p, env_begin, env_end, a.actions, (T*)a.pos,
+                       (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
+}
+
+// Full tiles run the straight-line FULL instantiation; the ragged tail (and every wave when the
+// per-step output blocks are not 16-byte aligned, i.e. B % 4 != 0) runs the guarded 64-wide one.
+template <typename T, class Cfg, bool CLAMP, int MODE, bool INFO, int EPW>
+static void launch_epw(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, const StepArgs& a, hipStream_t st) {
+    const long long n_full = ((B & 3) == 0) ? (B / EPW) * EPW : 0;
+    launch_range<T, Cfg, CLAMP, MODE, true, INFO, EPW>(p, 0, n_full, a, st);
+    launch_range<T, Cfg, CLAMP, MODE, false, INFO, 64>(p, n_full, B, a, st);
+}
+
+// Every launch uses 64-env tiles: 32- and 16-env tiles were measured at 65 536 and 262 144 envs and
+// lose 15 % / 50 % (a wave's instruction stream is as long whatever its tile, so narrower tiles only
+// multiply the instructions issued).
+template <typename T, class Cfg, bool CLAMP, int MODE, bool INFO>
+static void launch_mode(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, const StepArgs& a, hipStream_t st) {
+    launch_epw<T, Cfg, CLAMP, MODE, INFO, 64>(p, B, a, st);
+}
+
+template <typename T, class Cfg, bool CLAMP>
+static hipError_t launch_cfg(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
+    const auto p = make_params<T, Cfg>(s, B);
+    const bool info = a.info_i != nullptr;
+    switch (mode) {
+        case MODE_STEP:
+            info ? launch_mode<T, Cfg, CLAMP, MODE_STEP, true>(p, B, a, st) : launch_mode<T, Cfg, CLAMP, MODE_STEP, false>(p, B, a, st);
+            break;
+        case MODE_ROLLOUT:
+            info ? launch_mode<T, Cfg, CLAMP, MODE_ROLLOUT, true>(p, B, a, st) : launch_mode<T, Cfg, CLAMP, MODE_ROLLOUT, false>(p, B, a, st);
+            break;
+        default:
+            info ? launch_mode<T, Cfg, CLAMP, MODE_OBSERVE, true>(p, B, a, st) : launch_mode<T, Cfg, CLAMP, MODE_OBSERVE, false>(p, B, a, st);
+            break;
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_small_t(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
+    const bool clamp = s.any_speed_limit();
+    switch (s.scenario) {
+        case MPE_SCN_SPREAD:
+            return clamp ? launch_cfg<T, SpreadCfg<3, 3>, true>(s, B, mode, a, st) : launch_cfg<T, SpreadCfg<3, 3>, false>(s, B, mode, a, st);
+        case MPE_SCN_TAG:
+            return launch_cfg<T, TagCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_WORLD_COMM:
+            return launch_cfg<T, WorldCommCfg, true>(s, B, mode, a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mpe

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpe_hip.so")
+# MPE_HIP_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "libmpe_hip.so")
 
 MPE_F32, MPE_F64 = 0, 1
 SCN_NONE, SCN_SPREAD, SCN_TAG, SCN_WORLD_COMM = 0, 1, 2, 3

@@ -23,6 +23,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -53,7 +54,8 @@ def main():
     os.environ.update(env)
     bench = ["python3", "bench.py", "--no-cpu-baseline", "--scenario", args.scenario, "--envs", str(args.envs),
              "--dtype", args.dtype, "--mode", args.mode] + [a for a in extra if a != "--"]
-    mode_tag = {"rollout": ", 1>(", "step": ", 0>(", "graph": ", 0>("}[args.mode]   # MODE template argument
+    # small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>: MODE 1 = rollout, 0 = step
+    mode_re = re.compile(r">, (?:true|false), %s, (?:true|false), (?:true|false), \d+>\(" % {"rollout": "1", "step": "0", "graph": "0"}[args.mode])
     kern = args.kernel or "small_kernel<%s" % ("float" if args.dtype == "f32" else "double")
 
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(out, "stats"), "--"] + bench,
@@ -78,7 +80,7 @@ def main():
         vals = []
         for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(fn)):
-                if r["Counter_Name"] == counter and kern in r["Kernel_Name"] and mode_tag in r["Kernel_Name"]:
+                if r["Counter_Name"] == counter and kern in r["Kernel_Name"] and mode_re.search(r["Kernel_Name"]):
                     vals.append(float(r["Counter_Value"]))
         res[counter] = (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
     fetch_kib, n_f = res["FETCH_SIZE"]
