@@ -11,14 +11,16 @@ env reset on device at each episode boundary.  Envs shard by index across GPUs w
 collective (weak scaling: the per-GPU batch is fixed).
 
 Launch modes (--mode):
-  rollout  one mpe_rollout launch per 25-step episode (default: the headline number)
+  rollout  one mpe_episode launch per 25-step episode: on-device reset + 25 steps (default: the
+           headline number)
   step     one mpe_step launch per step, issued eagerly from Python (host-bound)
   graph    one mpe_step launch per step, the 25 launches of an episode replayed as one hipGraph
            (what an RL loop with a captured policy between steps would issue)
 
 Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   roofline      HBM roofline of the dominant kernel; achieved = algorithmic bytes per launch /
-                average launch duration from HIP events around every launch of the timed region
+                average launch duration from HIP events bracketing launches of the timed region
+                (every 4th launch by default, see --event-every)
   cpu_baseline  the single-env numpy oracle (oracle/mpe_oracle.py) timed on this host, 1 core
   step_mode     the same workload issued as one mpe_step launch per step (hipGraph), for comparison
 """
@@ -85,6 +87,9 @@ def main():
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step", "graph"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-mode", action="store_true")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="bracket every k-th episode launch with HIP events (markers around every launch cost ~7 us each "
+                         "and would throttle submission; the sampled average agrees with rocprofv3's per-kernel average)")
     args = ap.parse_args()
 
     import torch
@@ -139,14 +144,18 @@ def main():
         nonlocal out
         done_steps, launches, ep = 0, 0, 0
         while done_steps < n_steps:
-            env.reset(seed=1234 + first_env, observe=(mode != "rollout"))
             n = min(EPISODE, n_steps - done_steps)
+            if mode != "rollout":
+                env.reset(seed=1234 + first_env)
             if mode == "rollout":
-                if record:
+                rec = record and (launches % args.event_every == 0)
+                if rec:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                out = env.rollout(actions[:n], out if (out is not None and out["obs"].shape[0] == n) else None)
-                if record:
+                # mpe_episode: on-device reset of every env + n steps in one launch
+                out = env.rollout(actions[:n], out if (out is not None and out["obs"].shape[0] == n) else None,
+                                  reset_seed=1234 + first_env)
+                if rec:
                     e1.record()
                     pairs.append((e0, e1, n))
                 launches += 1
@@ -253,7 +262,7 @@ def main():
             "config": {"workload": "%s A=%d L=%d, %d envs/GPU, %d-step episodes, uniform random int actions, on-device reset each episode"
                                    % (args.scenario, A, env.n_landmarks, B, EPISODE),
                        "envs_per_gpu": B, "global_envs": world * B, "episode_steps": EPISODE,
-                       "launch": {"rollout": "mpe_rollout, %d steps/launch" % EPISODE, "step": "mpe_step, 1 step/launch, eager",
+                       "launch": {"rollout": "mpe_episode (on-device reset + %d steps) per launch" % EPISODE, "step": "mpe_step, 1 step/launch, eager",
                                   "graph": "mpe_step, 1 step/launch, %d launches per hipGraph replay" % EPISODE}[args.mode],
                        "parallelism": "env-index shards, no data-path collective"},
             "env_steps_per_s": value / A,

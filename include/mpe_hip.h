@@ -136,6 +136,17 @@ int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void
                 void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps,
                 mpe_stream_t stream);
 
+/*
+ * One whole episode in one launch: Scenario.reset_world for every env (the draws of
+ * mpe_reset(h, seed, episode, NULL, ...)) followed by n_steps MultiAgentEnv.step calls as in
+ * mpe_rollout.  pos / vel / comm need not be initialised; they hold the final state on return.
+ * The observation of the freshly reset state is not produced (call mpe_reset + mpe_observe +
+ * mpe_rollout when the policy needs it).
+ */
+int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos,
+                void* vel, void* comm, void* obs, void* rew, uint8_t* done, int32_t* info_i,
+                void* info_f, int32_t n_steps, mpe_stream_t stream);
+
 /* The scenario callbacks on the current state, without stepping: observation for every agent
  * (what MultiAgentEnv.reset returns, environment.py:122-127) and, when rew is not NULL, also
  * reward (environment.py:149-152) and benchmark_data (info_i / info_f, NULL to skip). */

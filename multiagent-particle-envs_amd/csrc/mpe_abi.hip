@@ -222,6 +222,13 @@ int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void
     return run(h, 1, a, stream, "mpe_rollout");
 }
 
+int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
+                void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps, mpe_stream_t stream) {
+    StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_steps};
+    if (h) a.reset = ResetArgs{1, seed, episode, landmark_limit(h->spec)};
+    return run(h, 1, a, stream, "mpe_episode");
+}
+
 int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs, void* rew, int32_t* info_i,
                 void* info_f, mpe_stream_t stream) {
     if (h && !rew && (info_i || info_f)) return fail(h, MPE_ERR_INVALID, "mpe_observe: info_i / info_f require rew");

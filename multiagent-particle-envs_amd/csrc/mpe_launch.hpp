@@ -32,6 +32,13 @@ struct DevTable {
     uint8_t collide[MAX_E], movable[MAX_E], silent[MPE_MAX_AGENTS];
 };
 
+// On-device Scenario.reset_world fused into the start of a rollout launch (mpe_episode).
+struct ResetArgs {
+    int enabled;
+    unsigned long long seed, episode;
+    double landmark_lim;      // landmarks ~ U(-lim, lim)^2; agents always U(-1, 1)^2
+};
+
 struct StepArgs {
     const int32_t* actions;
     void *pos, *vel, *comm, *obs, *rew;
@@ -39,7 +46,12 @@ struct StepArgs {
     int32_t* info_i;
     void* info_f;
     int n_steps;
+    ResetArgs reset;
 };
+
+// simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112
+// from U(-0.9,0.9).
+inline double landmark_limit(const HostSpec& s) { return (s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM) ? 0.9 : 1.0; }
 
 // small in-register scenarios (mpe_small.hip); mode: 0 step, 1 rollout, 2 observe
 bool small_supported(const HostSpec& s);

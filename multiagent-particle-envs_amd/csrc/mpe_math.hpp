@@ -171,4 +171,19 @@ struct Philox {
     }
 };
 
+// Position of entity `e` of world `b` in episode rs.episode: the two coordinates come from the
+// Philox block with key = seed and counter = (b, episode * 256 + e), mapped like numpy's
+// uniform(low, high) = low + (high - low) * random_sample().  Shared by reset_kernel and the
+// fused reset of the rollout kernels so both produce the same worlds.
+template <class RS>
+__host__ __device__ inline V2<double> reset_draw(const RS& rs, unsigned long long b, int e, bool is_agent) {
+    uint32_t r[4];
+    Philox::block(rs.seed, b, rs.episode * 256ull + (unsigned long long)e, r);
+    const double lim = is_agent ? 1.0 : rs.landmark_lim;
+    V2<double> d;
+    d.x = -lim + (lim + lim) * Philox::u01(r[0], r[1]);
+    d.y = -lim + (lim + lim) * Philox::u01(r[2], r[3]);
+    return d;
+}
+
 }  // namespace mpe

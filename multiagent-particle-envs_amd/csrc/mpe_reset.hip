@@ -9,8 +9,7 @@
 namespace mpe {
 
 template <typename T>
-__global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, int comm_rows, bool env_major, double landmark_lim,
-                                                    unsigned long long seed, unsigned long long episode,
+__global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, int comm_rows, bool env_major, const ResetArgs rs,
                                                     const uint8_t* __restrict__ mask, T* __restrict__ pos,
                                                     T* __restrict__ vel, T* __restrict__ comm) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -19,12 +18,9 @@ __global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, i
     // element (row r of n_rows, env b): env-minor r*B + b, env-major b*n_rows + r
     auto at = [=](int r, int n_rows) -> long long { return env_major ? b * n_rows + r : (long long)r * B + b; };
     for (int e = 0; e < E; ++e) {
-        uint32_t r[4];
-        Philox::block(seed, (uint64_t)b, episode * 256ull + (uint64_t)e, r);
-        const double lim = e < A ? 1.0 : landmark_lim;
-        // numpy uniform(low, high) = low + (high - low) * random_sample()
-        pos[at(2 * e, 2 * E)] = (T)(-lim + (lim + lim) * Philox::u01(r[0], r[1]));
-        pos[at(2 * e + 1, 2 * E)] = (T)(-lim + (lim + lim) * Philox::u01(r[2], r[3]));
+        const V2<double> d = reset_draw(rs, (unsigned long long)b, e, e < A);
+        pos[at(2 * e, 2 * E)] = (T)d.x;
+        pos[at(2 * e + 1, 2 * E)] = (T)d.y;
     }
     for (int r = 0; r < 2 * A; ++r) vel[at(r, 2 * A)] = T(0);
     for (int r = 0; r < comm_rows; ++r) comm[at(r, comm_rows)] = T(0);
@@ -32,14 +28,12 @@ __global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, i
 
 hipError_t launch_reset(const HostSpec& s, long long B, int dtype, int comm_rows, bool env_major, unsigned long long seed,
                         unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, hipStream_t st) {
-    // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and
-    // simple_world_comm.py:106-112 from U(-0.9,0.9).
-    const double lim = (s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM) ? 0.9 : 1.0;
+    const ResetArgs rs{1, seed, episode, landmark_limit(s)};
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
     if (dtype == MPE_F64)
-        hipLaunchKernelGGL(reset_kernel<double>, grid, block, 0, st, B, s.E(), s.A, comm_rows, env_major, lim, seed, episode, mask, (double*)pos, (double*)vel, (double*)comm);
+        hipLaunchKernelGGL(reset_kernel<double>, grid, block, 0, st, B, s.E(), s.A, comm_rows, env_major, rs, mask, (double*)pos, (double*)vel, (double*)comm);
     else
-        hipLaunchKernelGGL(reset_kernel<float>, grid, block, 0, st, B, s.E(), s.A, comm_rows, env_major, lim, seed, episode, mask, (float*)pos, (float*)vel, (float*)comm);
+        hipLaunchKernelGGL(reset_kernel<float>, grid, block, 0, st, B, s.E(), s.A, comm_rows, env_major, rs, mask, (float*)pos, (float*)vel, (float*)comm);
     return hipGetLastError();
 }
 

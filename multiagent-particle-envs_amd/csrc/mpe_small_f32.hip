@@ -6,3 +6,4 @@ hipError_t launch_small_f32(const HostSpec& s, long long B, int mode, const Step
     return launch_small_t<float>(s, B, mode, a, st);
 }
 }  // namespace mpe
+

@@ -17,6 +17,7 @@ namespace mpe {
 
 enum { MODE_STEP = 0, MODE_ROLLOUT = 1, MODE_OBSERVE = 2 };
 
+
 // ---- wave-private LDS tile holding W values for each of the wave's ROWS consecutive envs --------
 // Lane l writes its env's row, then the wave streams the tile to the env-major global array.
 //
@@ -75,9 +76,11 @@ struct Tile {
 // EPW: envs per wave (tile rows); 64 uses every lane.
 // FULL: every wave of the launch owns EPW valid envs and all output blocks are 16-byte aligned.
 // INFO: info_i / info_f are written.  env_begin / env_end: the env range this launch covers.
+// rs.enabled (rollout launches only): instead of loading the state, draw a fresh one exactly as
+//   reset_kernel would (Scenario.reset_world), so an episode is a single launch.
 template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW>
-__global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const long long env_begin,
-                                                   const long long env_end,
+__global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs,
+                                                   const long long env_begin, const long long env_end,
                                                    const int* __restrict__ actions, T* __restrict__ pos_g,
                                                    T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                    T* __restrict__ obs_g, T* __restrict__ rew_g,
@@ -107,15 +110,33 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     V2<T> pos[E];
     V2<T> vel[A];
     T comm[DC > 0 ? DC : 1];
+    if (MODE == MODE_ROLLOUT && rs.enabled) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        pos[e].x = pos_g[(long long)(2 * e) * B + b];
-        pos[e].y = pos_g[(long long)(2 * e + 1) * B + b];
-    }
+        for (int e = 0; e < E; ++e) {
+            const V2<double> d = reset_draw(rs, (unsigned long long)b, e, e < A);
+            pos[e].x = (T)d.x;
+            pos[e].y = (T)d.y;
+        }
 #pragma unroll
-    for (int i = 0; i < A; ++i) {
-        vel[i].x = vel_g[(long long)(2 * i) * B + b];
-        vel[i].y = vel_g[(long long)(2 * i + 1) * B + b];
+        for (int i = 0; i < A; ++i) { vel[i].x = T(0); vel[i].y = T(0); }
+        if (valid) {     // landmarks are not written back by the step loop: publish them now
+#pragma unroll
+            for (int e = A; e < E; ++e) {
+                pos_g[(long long)(2 * e) * B + b] = pos[e].x;
+                pos_g[(long long)(2 * e + 1) * B + b] = pos[e].y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            pos[e].x = pos_g[(long long)(2 * e) * B + b];
+            pos[e].y = pos_g[(long long)(2 * e + 1) * B + b];
+        }
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            vel[i].x = vel_g[(long long)(2 * i) * B + b];
+            vel[i].y = vel_g[(long long)(2 * i + 1) * B + b];
+        }
     }
     if (DC > 0) {
 #pragma unroll
@@ -252,7 +273,7 @@ template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int
 static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_begin, long long env_end, const StepArgs& a, hipStream_t st) {
     if (env_end <= env_begin) return;
     const dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
-    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>), grid, block, 0, st, p, env_begin, env_end, a.actions, (T*)a.pos,
+    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>), grid, block, 0, st, p, a.reset, env_begin, env_end, a.actions, (T*)a.pos,
                        (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
 }
 

@@ -31,7 +31,7 @@ struct WaveParams {
 template <typename T> __device__ __forceinline__ T spread_round(T v) { return (T)(float)v; }
 
 template <typename T, int EPI, int MODE, bool CLAMP>
-__global__ __launch_bounds__(64) void wave_kernel(const WaveParams<T> p, const int* __restrict__ actions,
+__global__ __launch_bounds__(64) void wave_kernel(const WaveParams<T> p, const ResetArgs rs, const int* __restrict__ actions,
                                                   const T* __restrict__ u_g, const T* __restrict__ c_g,
                                                   T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                   T* __restrict__ obs_g, T* __restrict__ rew_g, uint8_t* __restrict__ done_g,
@@ -51,13 +51,23 @@ __global__ __launch_bounds__(64) void wave_kernel(const WaveParams<T> p, const i
 
     // ---- stage the world ----
     for (int e = lane; e < E; e += 64) {
-        P[e].x = pos_g[b * (2 * E) + 2 * e];
-        P[e].y = pos_g[b * (2 * E) + 2 * e + 1];
+        if (rs.enabled) {       // fused Scenario.reset_world (same draws as reset_kernel)
+            const V2<double> d = reset_draw(rs, (unsigned long long)b, e, e < A);
+            P[e].x = (T)d.x;
+            P[e].y = (T)d.y;
+            if (e >= A) {       // landmarks are not written back by the step loop
+                pos_g[b * (2 * E) + 2 * e] = P[e].x;
+                pos_g[b * (2 * E) + 2 * e + 1] = P[e].y;
+            }
+        } else {
+            P[e].x = pos_g[b * (2 * E) + 2 * e];
+            P[e].y = pos_g[b * (2 * E) + 2 * e + 1];
+        }
         size_s[e] = (T)tb->size[e];
     }
     if (lane < A) {
-        Vel[lane].x = vel_g[b * (2 * A) + 2 * lane];
-        Vel[lane].y = vel_g[b * (2 * A) + 2 * lane + 1];
+        Vel[lane].x = rs.enabled ? T(0) : vel_g[b * (2 * A) + 2 * lane];
+        Vel[lane].y = rs.enabled ? T(0) : vel_g[b * (2 * A) + 2 * lane + 1];
     }
     if (lane == 0) {
         int n = 0;
@@ -195,10 +205,10 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
     p.A = s.A; p.L = s.L; p.dim_c = s.dim_c; p.n_speak_rows = n_speak_rows;
     const dim3 grid((unsigned)B), block(64);
     if (s.any_speed_limit())
-        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, true>), grid, block, 0, st, p, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
+        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, true>), grid, block, 0, st, p, a.reset, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
                            (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
     else
-        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false>), grid, block, 0, st, p, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
+        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false>), grid, block, 0, st, p, a.reset, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
                            (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
     return hipGetLastError();
 }

@@ -52,6 +52,7 @@ EXPORTS = {
     "mpe_last_error": (C.c_char_p, [C.c_void_p]),
     "mpe_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]),
     "mpe_rollout": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
+    "mpe_episode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
     "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
     "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 4 + [C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),

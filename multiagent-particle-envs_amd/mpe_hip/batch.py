@@ -121,9 +121,11 @@ class BatchedEnv:
                                                p["info_i"], p["info_f"], self._stream()))
         return self.obs, self.rew, self.done, (self.info_i, self.info_f)
 
-    def rollout(self, actions, out=None):
+    def rollout(self, actions, out=None, reset_seed=None):
         """``T`` steps in one launch for pre-computed actions ``[T, B, n_act]``.  Returns a dict of
-        ``[T, ...]`` tensors (pass the previous result as ``out`` to reuse its buffers)."""
+        ``[T, ...]`` tensors (pass the previous result as ``out`` to reuse its buffers).  With
+        ``reset_seed`` every env is first reset on device inside the same launch (one episode per
+        launch, like ``reset(seed, observe=False)`` followed by ``rollout``)."""
         T = int(actions.shape[0])
         a = self._actions(actions, (T,))
         lo, B = self.layout, self.n_envs
@@ -133,9 +135,15 @@ class BatchedEnv:
                    "info_i": z(T, B, lo.n_info_i, dt=torch.int32) if self.info_i is not None else None,
                    "info_f": z(T, B, lo.n_info_f) if self.info_f is not None else None}
         p = self._p
-        _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], _ptr(out["obs"]),
-                                                  _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]), _ptr(out["info_f"]), T,
-                                                  self._stream()))
+        if reset_seed is None:
+            _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], _ptr(out["obs"]),
+                                                      _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]), _ptr(out["info_f"]), T,
+                                                      self._stream()))
+        else:
+            _lib.check(self._h, self._lib.mpe_episode(self._h, int(reset_seed), self._episode, _ptr(a), p["pos"], p["vel"], p["comm"],
+                                                      _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]),
+                                                      _ptr(out["info_f"]), T, self._stream()))
+            self._episode += 1
         return out
 
     # ------------------------------------------------------------------

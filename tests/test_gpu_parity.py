@@ -311,3 +311,22 @@ def test_world_step_physics_only_matches_oracle(scn):
     assert _close(g_vel, vel, 1e-9, 1e-12)
     if speakers:
         assert np.array_equal(g_comm, comm[:, speakers, :].reshape(B, -1))
+
+
+@pytest.mark.parametrize("case", SMALL_CASES + ["spread64"])
+def test_episode_equals_reset_then_rollout(case):
+    """mpe_episode (reset fused into the rollout launch) against mpe_reset + mpe_rollout."""
+    g = load_golden(case)
+    B = 200 if case != "spread64" else 6
+    a = torch.as_tensor(np.resize(g["actions"], (7, B, g["actions"].shape[2]))).to("cuda:0")
+    for dt in (torch.float32, torch.float64):
+        e1, e2 = _env(case, B, dt), _env(case, B, dt)
+        e1.reset(seed=9, observe=False)
+        o1 = e1.rollout(a)
+        o2 = e2.rollout(a, reset_seed=9)
+        assert torch.equal(o1["obs"], o2["obs"]) and torch.equal(o1["rew"], o2["rew"])
+        assert torch.equal(o1["info_i"], o2["info_i"])
+        assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.vel, e2.vel)
+        # a second episode draws new worlds
+        o3 = e2.rollout(a, reset_seed=9)
+        assert not torch.equal(o3["obs"][0], o2["obs"][0])
