@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--landmarks", type=int, default=3)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step", "graph"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (a one-GPU box cannot host the real N > 1 run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-mode", action="store_true")
     ap.add_argument("--event-every", type=int, default=4,
@@ -100,11 +103,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import mpe_hip
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
