@@ -30,7 +30,8 @@
  *   obs      T[B][obs_total] per env, the agents' observation vectors concatenated in agent order;
  *                            agent i owns columns [obs_offset[i], obs_offset[i] + obs_dim[i])
  *   rew      T[B][A]
- *   done     uint8[B]        always 0: no in-scope scenario has a done callback (environment.py:143-146)
+ *   done     uint8[B]        0: no in-scope scenario has a done callback (environment.py:143-146);
+ *                            mpe_step_auto sets it to 1 on the step that reaches its time limit
  *   info_i   int32[B][n_info_i]   optional (NULL to skip), see mpe_layout
  *   info_f   T[B][n_info_f]       optional (NULL to skip)
  */
@@ -124,6 +125,22 @@ const char* mpe_last_error(const MpeHandle* h);
  */
 int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
              void* rew, uint8_t* done, int32_t* info_i, void* info_f, mpe_stream_t stream);
+
+/*
+ * mpe_step plus the episode bookkeeping the reference leaves to its caller (the runner loop of
+ * backup/runner_old.py:44-56 resets an env when it is done; baselines' Monitor sums the episode
+ * return): per env, ep_return T[B][A] accumulates the rewards and step_count int32[B] counts the
+ * steps of the running episode.  When step_count reaches max_steps the episode is truncated:
+ * done[b] = 1, last_return[b] receives the finished return, ep_return and step_count restart at 0,
+ * episode_count int32[B] is incremented and the env is reset on device with the draws of
+ * mpe_reset(h, seed, episode_count[b], ...), so obs holds the first observation of the new episode
+ * (rew and info still describe the step that ended the old one).  All four bookkeeping arrays are
+ * caller-owned device buffers, zero-initialised by the caller before the first episode.
+ */
+int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
+                  void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t* step_count,
+                  int32_t* episode_count, void* ep_return, void* last_return, int32_t max_steps,
+                  uint64_t seed, mpe_stream_t stream);
 
 /*
  * n_steps consecutive MultiAgentEnv.step calls in one launch, for pre-computed actions (the

@@ -216,6 +216,18 @@ int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* c
     return run(h, 0, a, stream, "mpe_step");
 }
 
+int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs, void* rew, uint8_t* done,
+                  int32_t* info_i, void* info_f, int32_t* step_count, int32_t* episode_count, void* ep_return, void* last_return,
+                  int32_t max_steps, uint64_t seed, mpe_stream_t stream) {
+    if (!h) return MPE_ERR_INVALID;
+    if (!step_count || !episode_count || !ep_return || !last_return)
+        return fail(h, MPE_ERR_INVALID, "mpe_step_auto: step_count, episode_count, ep_return and last_return must not be NULL");
+    if (max_steps < 1) return fail(h, MPE_ERR_INVALID, "mpe_step_auto: max_steps must be >= 1");
+    StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, 1};
+    a.au = AutoArgs{step_count, episode_count, ep_return, last_return, max_steps, seed, landmark_limit(h->spec)};
+    return run(h, 0, a, stream, "mpe_step_auto");
+}
+
 int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs, void* rew,
                 uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps, mpe_stream_t stream) {
     const StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_steps};

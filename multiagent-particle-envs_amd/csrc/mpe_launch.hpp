@@ -39,6 +39,17 @@ struct ResetArgs {
     double landmark_lim;      // landmarks ~ U(-lim, lim)^2; agents always U(-1, 1)^2
 };
 
+// Episode bookkeeping of mpe_step_auto (all pointers NULL = plain mpe_step).
+struct AutoArgs {
+    int32_t* step_count;      // [B] steps taken in the running episode
+    int32_t* episode_count;   // [B] number of the running episode (keys the reset draws)
+    void* ep_return;          // T[B][A] running return
+    void* last_return;        // T[B][A] return of the last finished episode
+    int max_steps;
+    unsigned long long seed;
+    double landmark_lim;
+};
+
 struct StepArgs {
     const int32_t* actions;
     void *pos, *vel, *comm, *obs, *rew;
@@ -47,6 +58,7 @@ struct StepArgs {
     void* info_f;
     int n_steps;
     ResetArgs reset;
+    AutoArgs au;
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112

@@ -46,17 +46,8 @@ struct Tile {
             const VT* src = reinterpret_cast<const VT*>(tile);
             VT* dst = reinterpret_cast<VT*>(gdst);
 #pragma unroll
-#if defined(MPE_PROBE_NO_STORES)   // diagnostic build: LDS reads kept alive, nothing written
-            for (int it = 0; it < FULL_IT; ++it) { VT v = src[it * 64 + lane]; asm volatile("" :: "v"(v)); }
-            if (REM > 0 && lane < REM) { VT v = src[FULL_IT * 64 + lane]; asm volatile("" :: "v"(v)); }
-            (void)dst;
-#elif defined(MPE_NT_STORES)
-            for (int it = 0; it < FULL_IT; ++it) __builtin_nontemporal_store(src[it * 64 + lane], &dst[it * 64 + lane]);
-            if (REM > 0 && lane < REM) __builtin_nontemporal_store(src[FULL_IT * 64 + lane], &dst[FULL_IT * 64 + lane]);
-#else
             for (int it = 0; it < FULL_IT; ++it) dst[it * 64 + lane] = src[it * 64 + lane];
             if (REM > 0 && lane < REM) dst[FULL_IT * 64 + lane] = src[FULL_IT * 64 + lane];
-#endif
         } else {
             const int n = nvalid * W;
 #pragma unroll
@@ -79,7 +70,7 @@ struct Tile {
 // rs.enabled (rollout launches only): instead of loading the state, draw a fresh one exactly as
 //   reset_kernel would (Scenario.reset_world), so an episode is a single launch.
 template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW>
-__global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs,
+__global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs, const AutoArgs au,
                                                    const long long env_begin, const long long env_end,
                                                    const int* __restrict__ actions, T* __restrict__ pos_g,
                                                    T* __restrict__ vel_g, T* __restrict__ comm_g,
@@ -214,19 +205,60 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 
         // ---- scenario callbacks into the wave's LDS tiles ----
         const bool want_score = (MODE != MODE_OBSERVE) || (rew_g != nullptr);   // observe: rewards on request
+        bool finished = false;
         if (EPW == 64 || lane < EPW) {
-            Cfg::template observe<T>(pos, vel, comm, p, ObsTile::row(tile_obs, tile_lane));
             if (want_score)
                 Cfg::template score<T>(pos, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
+            if (MODE == MODE_STEP && au.step_count != nullptr) {
+                // ---- episode bookkeeping (mpe_step_auto): returns, step counter, time-limit reset ----
+                T* ep = (T*)au.ep_return + b * A;
+                const T* rrow = RewTile::row(tile_rew, tile_lane);
+                const int cnt = au.step_count[b] + 1;
+                finished = cnt >= au.max_steps;
+                T total[A];
+#pragma unroll
+                for (int i = 0; i < A; ++i) total[i] = ep[i] + rrow[i];
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < A; ++i) {
+                        ep[i] = finished ? T(0) : total[i];
+                        if (finished) ((T*)au.last_return)[b * A + i] = total[i];
+                    }
+                    au.step_count[b] = finished ? 0 : cnt;
+                }
+                if (finished) {       // Scenario.reset_world with the next episode's draws; obs below is the fresh one
+                    const int epi = au.episode_count[b] + 1;
+                    if (valid) au.episode_count[b] = epi;
+                    const ResetArgs nr{1, au.seed, (unsigned long long)epi, au.landmark_lim};
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const V2<double> d = reset_draw(nr, (unsigned long long)b, e, e < A);
+                        pos[e].x = (T)d.x;
+                        pos[e].y = (T)d.y;
+                    }
+#pragma unroll
+                    for (int i = 0; i < A; ++i) { vel[i].x = T(0); vel[i].y = T(0); }
+                    if (DC > 0) {
+#pragma unroll
+                        for (int c = 0; c < DC; ++c) comm[c] = T(0);
+                    }
+                    if (valid) {
+#pragma unroll
+                        for (int e = A; e < E; ++e) {
+                            pos_g[(long long)(2 * e) * B + b] = pos[e].x;
+                            pos_g[(long long)(2 * e + 1) * B + b] = pos[e].y;
+                        }
+                    }
+                }
+            }
+            Cfg::template observe<T>(pos, vel, comm, p, ObsTile::row(tile_obs, tile_lane));
         }
         __syncthreads();
         const long long row0 = (long long)t * B + env0;
         ObsTile::template flush<FULL>(tile_obs, obs_g + row0 * OT, lane, nvalid);
         if (want_score) {
             RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane, nvalid);
-#ifndef MPE_NO_DONE
-            if (MODE != MODE_OBSERVE && valid) done_g[row0 + lane] = 0;
-#endif
+            if (MODE != MODE_OBSERVE && valid) done_g[row0 + lane] = finished ? 1 : 0;
             if (want_info) {
                 IiTile::template flush<FULL>(tile_ii, info_i_g + row0 * NI, lane, nvalid);
                 if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::template flush<FULL>(tile_if, info_f_g + row0 * NF, lane, nvalid);
@@ -273,7 +305,7 @@ template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int
 static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_begin, long long env_end, const StepArgs& a, hipStream_t st) {
     if (env_end <= env_begin) return;
     const dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
-    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>), grid, block, 0, st, p, a.reset, env_begin, env_end, a.actions, (T*)a.pos,
+    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
                        (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
 }
 

@@ -34,7 +34,7 @@ struct WaveParams {
 template <typename T> __device__ __forceinline__ T spread_round(T v) { return (T)(float)v; }
 
 template <typename T, int EPI, int MODE, bool CLAMP>
-__global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const ResetArgs rs, const int* __restrict__ actions,
+__global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const ResetArgs rs, const AutoArgs au, const int* __restrict__ actions,
                                                   const T* __restrict__ u_g, const T* __restrict__ c_g,
                                                   T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                   T* __restrict__ obs_g, T* __restrict__ rew_g, uint8_t* __restrict__ done_g,
@@ -127,31 +127,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
         }
 
         if (EPI == EPI_SPREAD) {
-            // ---- observation(), simple_spread.py:110-130: rows of OD/2 coordinate pairs ----
-            const int RP = OD / 2, total = A * RP;
-            const float inv_rp = 1.0f / (float)RP;    // q <= 64 * 129: (q + 0.5) / RP floors exactly in float
-            T* obs_env = obs_g + row * (long long)(A * OD);
-            #pragma unroll 4
-            for (int q = lane; q < total; q += NT) {
-                const int i = (int)(((float)q + 0.5f) * inv_rp), r = q - i * RP;
-                V2<T> o;
-                if (r == 0) o = Vel[i];
-                else if (r == 1) o = P[i];
-                else {
-                    int src;
-                    if (r < 2 + L) src = A + (r - 2);
-                    else { const int m = r - 2 - L; src = m + (m >= i ? 1 : 0); }
-                    o.x = P[src].x - P[i].x;
-                    o.y = P[src].y - P[i].y;
-                }
-                // one 2-vector store per pair: the world's block starts at a multiple of A*OD values and
-                // OD is even, so pair q is 2*sizeof(T)-aligned
-                typedef T T2 __attribute__((ext_vector_type(2)));
-                T2 w;
-                w.x = spread_round<T>(o.x);
-                w.y = spread_round<T>(o.y);
-                reinterpret_cast<T2*>(obs_env)[q] = w;
-            }
+            bool finished = false;
             if (MODE != WMODE_OBSERVE || rew_g != nullptr) {
                 // ---- reward() :83-108 and benchmark_data() :58-74 ----
                 if (lane < L) {
@@ -177,7 +153,15 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                         if (a == lane) continue;
                         if (touching<T>(P[a], pi, size_s[a] + my_size)) { c += 1; bench = bench - T(1); }
                     }
-                    rew_g[row * A + lane] = (lane == 0 ? prox : T(0)) + (T)(-c);
+                    const T r_me = (lane == 0 ? prox : T(0)) + (T)(-c);
+                    rew_g[row * A + lane] = r_me;
+                    if (MODE == WMODE_STEP && au.step_count != nullptr) {
+                        T* ep = (T*)au.ep_return + b * A;
+                        const T total = ep[lane] + r_me;
+                        const bool fin = au.step_count[b] + 1 >= au.max_steps;
+                        ep[lane] = fin ? T(0) : total;
+                        if (fin) ((T*)au.last_return)[b * A + lane] = total;
+                    }
                     if (want_info) {
                         info_i_g[row * (A + 1) + lane] = c;
                         if (info_f_g) info_f_g[row * (A + 1) + 1 + lane] = bench;
@@ -190,7 +174,58 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                         }
                     }
                 }
-                __syncthreads();        // mind_s is rewritten by the next step
+                __syncthreads();        // mind_s is rewritten by the next step; P may be reset below
+            }
+            if (MODE == WMODE_STEP && au.step_count != nullptr) {
+                // ---- episode bookkeeping (mpe_step_auto): step counter and time-limit reset ----
+                const int cnt = au.step_count[b] + 1;       // read by every thread before thread 0 updates it
+                finished = cnt >= au.max_steps;
+                const int epi = au.episode_count[b] + (finished ? 1 : 0);
+                __syncthreads();
+                if (lane == 0) {
+                    au.step_count[b] = finished ? 0 : cnt;
+                    au.episode_count[b] = epi;
+                    done_g[row] = finished ? 1 : 0;
+                }
+                if (finished) {     // Scenario.reset_world with the next episode's draws
+                    const ResetArgs nr{1, au.seed, (unsigned long long)epi, au.landmark_lim};
+                    for (int e = lane; e < E; e += NT) {
+                        const V2<double> d = reset_draw(nr, (unsigned long long)b, e, e < A);
+                        P[e].x = (T)d.x;
+                        P[e].y = (T)d.y;
+                        if (e >= A) {
+                            pos_g[b * (2 * E) + 2 * e] = P[e].x;
+                            pos_g[b * (2 * E) + 2 * e + 1] = P[e].y;
+                        }
+                    }
+                    if (is_agent) { Vel[lane].x = T(0); Vel[lane].y = T(0); }
+                    __syncthreads();
+                }
+            }
+            // ---- observation(), simple_spread.py:110-130: rows of OD/2 coordinate pairs ----
+            const int RP = OD / 2, total = A * RP;
+            const float inv_rp = 1.0f / (float)RP;    // q <= 64 * 129: (q + 0.5) / RP floors exactly in float
+            T* obs_env = obs_g + row * (long long)(A * OD);
+            #pragma unroll 4
+            for (int q = lane; q < total; q += NT) {
+                const int i = (int)(((float)q + 0.5f) * inv_rp), r = q - i * RP;
+                V2<T> o;
+                if (r == 0) o = Vel[i];
+                else if (r == 1) o = P[i];
+                else {
+                    int src;
+                    if (r < 2 + L) src = A + (r - 2);
+                    else { const int m = r - 2 - L; src = m + (m >= i ? 1 : 0); }
+                    o.x = P[src].x - P[i].x;
+                    o.y = P[src].y - P[i].y;
+                }
+                // one 2-vector store per pair: the world's block starts at a multiple of A*OD values and
+                // OD is even, so pair q is 2*sizeof(T)-aligned
+                typedef T T2 __attribute__((ext_vector_type(2)));
+                T2 w;
+                w.x = spread_round<T>(o.x);
+                w.y = spread_round<T>(o.y);
+                reinterpret_cast<T2*>(obs_env)[q] = w;
             }
         }
     }
@@ -217,10 +252,10 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
     p.A = s.A; p.L = s.L; p.dim_c = s.dim_c; p.n_speak_rows = n_speak_rows;
     const dim3 grid((unsigned)B), block(NT);
     if (s.any_speed_limit())
-        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, true>), grid, block, 0, st, p, a.reset, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
+        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, true>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
                            (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
     else
-        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false>), grid, block, 0, st, p, a.reset, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
+        hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
                            (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
     return hipGetLastError();
 }

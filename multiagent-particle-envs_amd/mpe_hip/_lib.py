@@ -51,6 +51,7 @@ EXPORTS = {
     "mpe_layout": (C.c_int, [C.c_void_p, C.POINTER(MpeLayout)]),
     "mpe_last_error": (C.c_char_p, [C.c_void_p]),
     "mpe_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]),
+    "mpe_step_auto": (C.c_int, [C.c_void_p] + [C.c_void_p] * 13 + [C.c_int32, C.c_uint64, C.c_void_p]),
     "mpe_rollout": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
     "mpe_episode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
     "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),

@@ -31,7 +31,8 @@ class BatchedEnv:
     Actions are int32 ``[B, n_act]``: per agent its move 0..4, then its comm word if it speaks.
     """
 
-    def __init__(self, scenario, n_envs, dtype=torch.float32, device="cuda:0", info=False, **spec_kw):
+    def __init__(self, scenario, n_envs, dtype=torch.float32, device="cuda:0", info=False, max_episode_steps=None, seed=0,
+                 **spec_kw):
         self.spec = scenario if isinstance(scenario, WorldSpec) else make_spec(scenario, **spec_kw)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -66,8 +67,17 @@ class BatchedEnv:
         self.info_i = z(B, lo.n_info_i, dt=torch.int32) if info else None
         self.info_f = z(B, lo.n_info_f) if (info and lo.n_info_f > 0) else None
         self._episode = 0
+        # episode bookkeeping on device (mpe_step_auto): time-limit truncation + auto-reset + returns
+        self.max_episode_steps = max_episode_steps
+        self.seed = int(seed)
+        if max_episode_steps is not None:
+            self.step_count = z(B, dt=torch.int32)
+            self.episode_count = z(B, dt=torch.int32)
+            self.ep_return = z(B, A)
+            self.last_return = z(B, A)
         # raw device pointers of the persistent buffers, resolved once (the tensors are never reallocated)
-        self._p = {k: _ptr(getattr(self, k)) for k in ("pos", "vel", "comm", "obs", "rew", "done", "info_i", "info_f")}
+        self._p = {k: _ptr(getattr(self, k, None)) for k in ("pos", "vel", "comm", "obs", "rew", "done", "info_i", "info_f",
+                                                             "step_count", "episode_count", "ep_return", "last_return")}
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -100,6 +110,16 @@ class BatchedEnv:
         p = self._p
         _lib.check(self._h, self._lib.mpe_reset(self._h, int(seed), self._episode, _ptr(mask), p["pos"], p["vel"], p["comm"],
                                                 self._stream()))
+        if self.max_episode_steps is not None:
+            # the device-side counters restart from this reset: later automatic resets draw episodes
+            # self._episode + 1, + 2, ... of the same seed
+            self.seed = int(seed)
+            keep = None if mask is None else (mask == 0)
+            for t, v in ((self.step_count, 0), (self.episode_count, self._episode), (self.ep_return, 0)):
+                if keep is None:
+                    t.fill_(v)
+                else:
+                    t[~keep] = v
         self._episode += 1
         return self.observe() if observe else None
 
@@ -117,8 +137,15 @@ class BatchedEnv:
         overwritten by the next call."""
         a = self._actions(actions, ())
         p = self._p
-        _lib.check(self._h, self._lib.mpe_step(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["obs"], p["rew"], p["done"],
-                                               p["info_i"], p["info_f"], self._stream()))
+        if self.max_episode_steps is not None:
+            # envs that reach max_episode_steps are truncated (done = 1) and reset on device; obs is then the new
+            # episode's first observation, last_return the finished episode's return
+            _lib.check(self._h, self._lib.mpe_step_auto(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["obs"], p["rew"], p["done"],
+                                                        p["info_i"], p["info_f"], p["step_count"], p["episode_count"], p["ep_return"],
+                                                        p["last_return"], int(self.max_episode_steps), self.seed, self._stream()))
+        else:
+            _lib.check(self._h, self._lib.mpe_step(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["obs"], p["rew"], p["done"],
+                                                   p["info_i"], p["info_f"], self._stream()))
         return self.obs, self.rew, self.done, (self.info_i, self.info_f)
 
     def rollout(self, actions, out=None, reset_seed=None):

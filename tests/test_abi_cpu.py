@@ -17,7 +17,7 @@ def _declared():
 
 def test_header_declares_expected_entry_points():
     names = _declared()
-    for n in ("mpe_create", "mpe_destroy", "mpe_layout", "mpe_last_error", "mpe_step", "mpe_rollout", "mpe_episode",
+    for n in ("mpe_create", "mpe_destroy", "mpe_layout", "mpe_last_error", "mpe_step", "mpe_step_auto", "mpe_rollout", "mpe_episode",
               "mpe_observe", "mpe_reset", "mpe_world_step"):
         assert n in names
 

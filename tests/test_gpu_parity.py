@@ -330,3 +330,42 @@ def test_episode_equals_reset_then_rollout(case):
         # a second episode draws new worlds
         o3 = e2.rollout(a, reset_seed=9)
         assert not torch.equal(o3["obs"][0], o2["obs"][0])
+
+
+@pytest.mark.parametrize("case", SMALL_CASES + ["spread64"])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_step_auto_bookkeeping_and_reset(case, dtype):
+    """mpe_step_auto against plain mpe_step + host-side bookkeeping: returns, step counters,
+    time-limit truncation with on-device reset (the reset worlds equal mpe_reset's draws)."""
+    import mpe_hip
+    dt = getattr(torch, dtype)
+    scn, kw = GOLDEN_CASES[case]
+    kw = {("n_agents" if k == "A" else "n_landmarks"): v for k, v in kw.items()}
+    B, H = (130, 7) if case != "spread64" else (5, 4)
+    auto = mpe_hip.BatchedEnv(scn, B, dtype=dt, info=True, max_episode_steps=H, seed=21, **kw)
+    ref = mpe_hip.BatchedEnv(scn, B, dtype=dt, info=True, **kw)
+    obs_a = auto.reset(seed=21).clone()
+    obs_r = ref.reset(seed=21).clone()
+    assert torch.equal(obs_a, obs_r)
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(2)
+    ret = torch.zeros(B, auto.n_agents, dtype=dt, device="cuda:0")
+    for t in range(2 * H + 3):
+        a = torch.randint(0, 4, (B, auto.n_act), generator=gen, device="cuda:0", dtype=torch.int32)
+        oa, ra, da, (ia, fa) = auto.step(a)
+        o, r, d, (ii, ff) = ref.step(a)
+        assert torch.equal(ra, r) and torch.equal(ia, ii)
+        ret = ret + r
+        boundary = (t + 1) % H == 0
+        if boundary:
+            assert bool(da.all())
+            assert torch.equal(auto.last_return, ret)
+            assert float(auto.ep_return.abs().max()) == 0 and int(auto.step_count.max()) == 0
+            o = ref.reset(seed=21)                       # episode (t + 1) / H of the same seed
+            ret.zero_()
+            assert int(auto.episode_count.min()) == int(auto.episode_count.max()) == (t + 1) // H
+        else:
+            assert not bool(da.any())
+            assert torch.equal(auto.ep_return, ret) and int(auto.step_count.min()) == (t + 1) % H
+        assert torch.equal(oa, o)
+        assert torch.equal(auto.pos, ref.pos) and torch.equal(auto.vel, ref.vel)
