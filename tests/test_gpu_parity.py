@@ -369,3 +369,105 @@ def test_step_auto_bookkeeping_and_reset(case, dtype):
             assert torch.equal(auto.ep_return, ret) and int(auto.step_count.min()) == (t + 1) % H
         assert torch.equal(oa, o)
         assert torch.equal(auto.pos, ref.pos) and torch.equal(auto.vel, ref.vel)
+
+
+# ------------------------------------------------------------------------------------------
+# edge cases
+# ------------------------------------------------------------------------------------------
+def test_coincident_agents_give_nan_like_the_reference():
+    """dist == 0 makes the reference divide 0/0 (core.py:230); the NaN must propagate, not be fixed."""
+    spec = orc.spec_spread()
+    pos = np.zeros((4, 6, 2))
+    pos[:, 2:] = np.random.RandomState(0).uniform(-1, 1, (4, 4, 2))
+    pos[1, 1] = (0.4, 0.4)                               # env 1: no coincidence
+    vel = np.zeros((4, 3, 2))
+    act = np.array([[0, 0, 0], [1, 2, 3], [4, 4, 4], [0, 1, 0]])
+    with np.errstate(all="ignore"):
+        p, v, c, o_obs, o_rew, _ = orc.env_step(spec, pos, vel, act)
+    for dtype in (torch.float64, torch.float32):
+        env = _env("spread3", 4, dtype)
+        env.set_state(pos, vel)
+        obs, rew, done, _ = env.step(torch.as_tensor(act, dtype=torch.int32))
+        gp, gv, _ = env.get_state()
+        assert np.array_equal(np.isnan(gp), np.isnan(p)) and np.array_equal(np.isnan(gv), np.isnan(v))
+        assert np.isnan(gp[0, 0]).all() and not np.isnan(gp[1]).any() and not np.isnan(gp[:, 2]).any()
+        assert np.array_equal(np.isnan(obs.cpu().numpy()), np.isnan(np.concatenate(o_obs, 1)))
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_out_of_range_actions_are_noops(case):
+    """environment.py:178-181 only reacts to 1..4; any other int leaves u at zero."""
+    scn, kw = GOLDEN_CASES[case]
+    spec = orc.make_spec(scn, **kw)
+    B = 64
+    rng = np.random.RandomState(1)
+    pos = rng.uniform(-1, 1, (B, spec.E, 2))
+    vel = rng.uniform(-0.3, 0.3, (B, spec.A, 2))
+    act = rng.choice([-7, -1, 0, 5, 6, 9, 100, 2 ** 31 - 1, 1, 3], size=(B, spec.n_act))
+    if scn == "simple_world_comm":
+        act[:, 1] = rng.randint(0, 4, B)                 # the comm word must stay a valid index in the oracle
+    p, v, c, o_obs, o_rew, _ = orc.env_step(spec, pos, vel, act)
+    env = _env(case, B, torch.float64)
+    env.set_state(pos, vel)
+    obs, rew, done, _ = env.step(torch.as_tensor(act, dtype=torch.int32))
+    gp, gv, _ = env.get_state()
+    assert _close(gp, p, 1e-12, 1e-13) and _close(gv, v, 1e-12, 1e-13)
+    out = env.rollout(torch.as_tensor(act[None], dtype=torch.int32).to("cuda:0").contiguous())   # packed-action path
+    p2, v2, *_ = orc.env_step(spec, p, v, act)
+    gp2, gv2, _ = env.get_state()
+    assert _close(gp2, p2, 1e-12, 1e-13) and _close(gv2, v2, 1e-12, 1e-13)
+
+
+@pytest.mark.parametrize("case", SMALL_CASES + ["spread64"])
+def test_modified_world_constants_and_entity_properties(case):
+    """dt, damping, contact force / margin, sizes, masses, accelerations and speed limits are run-time
+    parameters: a world edited after make_world must be simulated with its own numbers."""
+    import mpe_hip
+    scn, kw = GOLDEN_CASES[case]
+    spec = orc.make_spec(scn, **kw)
+    rng = np.random.RandomState(4)
+    spec.dt, spec.damping, spec.contact_force, spec.contact_margin = 0.07, 0.4, 55.0, 2e-3
+    spec.size = spec.size * rng.uniform(0.7, 1.5, spec.E)
+    spec.mass = rng.uniform(0.5, 2.0, spec.E)
+    spec.sens = rng.uniform(2.0, 6.0, spec.A)
+    spec.max_speed = np.where(rng.rand(spec.A) < 0.5, rng.uniform(0.3, 0.9, spec.A), np.inf)
+    kwp = {("n_agents" if k == "A" else "n_landmarks"): v for k, v in kw.items()}
+    ps = mpe_hip.make_spec(scn, **kwp)
+    ps.dt, ps.damping, ps.contact_force, ps.contact_margin = spec.dt, spec.damping, spec.contact_force, spec.contact_margin
+    ps.size, ps.mass, ps.sensitivity, ps.max_speed = spec.size, spec.mass, spec.sens, spec.max_speed
+    B = 96 if spec.A <= 6 else 3
+    pos = np.concatenate([rng.uniform(-1, 1, (B, spec.A, 2)), rng.uniform(-0.9, 0.9, (B, spec.L, 2))], axis=1)
+    vel = rng.uniform(-1, 1, (B, spec.A, 2))
+    env = mpe_hip.BatchedEnv(ps, B, dtype=torch.float64, info=True)
+    env.set_state(pos, vel)
+    for t in range(8):
+        act = rng.randint(0, 5, (B, spec.n_act))
+        if scn == "simple_world_comm":
+            act[:, 1] = rng.randint(0, 4, B)
+        obs, rew, done, (ii, ff) = env.step(torch.as_tensor(act, dtype=torch.int32))
+        pos, vel, comm, o_obs, o_rew, _ = orc.env_step(spec, pos, vel, act)
+    gp, gv, _ = env.get_state()
+    assert _close(gp, pos, 1e-9, 1e-12), np.abs(gp - pos).max()
+    assert _close(gv, vel, 1e-9, 1e-12)
+    assert _close(rew.cpu().numpy(), o_rew, 1e-9, 1e-12)
+    assert np.array_equal(ii.cpu().numpy()[:, :spec.A], orc.info(spec, pos)["collisions"])
+
+
+def test_far_outside_the_arena_boundary_penalty_saturates():
+    """bound(x) = min(exp(2x - 2), 10) for x >= 1 (simple_tag.py:108): huge |x| must cap at 10, not overflow."""
+    spec = orc.spec_tag()
+    B = 8
+    pos = np.zeros((B, 6, 2))
+    pos[:, :3] = [(5, 5), (-5, 5), (5, -5)]
+    pos[:, 4:] = [(7, 7), (-7, -7)]
+    pos[:, 3, 0] = [0.5, 0.95, 1.0, 1.2, 2.16, 3.0, 50.0, 400.0]
+    pos[:, 3, 1] = [-0.5, -0.95, -1.0, -1.2, -2.16, -3.0, -50.0, -400.0]
+    vel = np.zeros((B, 4, 2))
+    act = np.zeros((B, 4), int)
+    p, v, c, o_obs, o_rew, _ = orc.env_step(spec, pos, vel, act)
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-6)):
+        env = _env("tag", B, dtype)
+        env.set_state(pos, vel)
+        obs, rew, done, _ = env.step(torch.as_tensor(act, dtype=torch.int32))
+        assert _close(rew.cpu().numpy(), o_rew, tol, tol), (rew.cpu().numpy()[:, 3], o_rew[:, 3])
+    assert o_rew[-1, 3] == -20.0 and o_rew[0, 3] == 0.0
