@@ -60,6 +60,7 @@ extern "C" {
 
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_LANDMARKS 64
+#define MPE_MAX_WALLS 16
 
 typedef void* mpe_stream_t; /* hipStream_t */
 
@@ -85,6 +86,17 @@ typedef struct MpeSpec {
     const uint8_t* silent;    /* [A] Agent.silent */
     const uint8_t* adversary; /* [A] agent.adversary (simple_tag.py:21); zeros otherwise */
     const uint8_t* leader;    /* [A] agent.leader (simple_world_comm.py:23); zeros otherwise */
+    /* World.walls (core.py:26-42), simulated by mpe_world_step only (MPE_SCN_NONE); n_walls == 0
+     * and NULL pointers for the built-in scenarios, none of which has walls. */
+    int32_t n_walls;
+    int32_t reserved;
+    const uint8_t* wall_vertical;  /* [W] 0: orient 'H' (lies along x at y = axis_pos), 1: orient 'V' */
+    const double* wall_axis_pos;   /* [W] Wall.axis_pos */
+    const double* wall_end0;       /* [W] Wall.endpoints[0] */
+    const double* wall_end1;       /* [W] Wall.endpoints[1] */
+    const double* wall_width;      /* [W] Wall.width */
+    const uint8_t* wall_hard;      /* [W] Wall.hard */
+    const uint8_t* ghost;          /* [A] Agent.ghost: passes through walls that are not hard (NULL = none) */
 } MpeSpec;
 
 /* Derived sizes of the caller-allocated buffers. */
@@ -184,7 +196,8 @@ int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask
  * World.step alone (core.py:142-158) for scenarios whose callbacks stay in Python (handles created
  * with MPE_SCN_NONE, env-major state): forces u T[B][2A] (already scaled, i.e. agent.action.u) and
  * comm actions c T[B][S*dim_c] (agent.action.c of the speakers, may be NULL if S == 0) are given
- * directly; pos, vel, comm are updated in place.  Walls are not simulated.
+ * directly; pos, vel, comm are updated in place.  Wall contact (get_wall_collision_force,
+ * core.py:270-307) is applied to every agent after its entity contacts, as in core.py:182-188.
  */
 int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* vel, void* comm,
                    mpe_stream_t stream);

@@ -141,7 +141,22 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
         s.silent[i] = spec->silent[i] ? 1 : 0;
         s.adversary[i] = (spec->adversary && spec->adversary[i]) ? 1 : 0;
         s.leader[i] = (spec->leader && spec->leader[i]) ? 1 : 0;
+        s.ghost[i] = (spec->ghost && spec->ghost[i]) ? 1 : 0;
         if (isnan(s.max_speed[i])) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: max_speed[%d] is NaN (use +inf for no limit)", i); }
+    }
+    s.n_walls = spec->n_walls;
+    if (s.n_walls < 0 || s.n_walls > MPE_MAX_WALLS) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: 0..%d walls (got %d)", MPE_MAX_WALLS, spec->n_walls); }
+    if (s.n_walls > 0) {
+        if (spec->scenario != MPE_SCN_NONE) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: walls are simulated by mpe_world_step only (MPE_SCN_NONE)"); }
+        if (!spec->wall_vertical || !spec->wall_axis_pos || !spec->wall_end0 || !spec->wall_end1 || !spec->wall_width || !spec->wall_hard) {
+            delete h;
+            return fail(nullptr, MPE_ERR_INVALID, "mpe_create: a wall array is NULL");
+        }
+        for (int w = 0; w < s.n_walls; ++w) {
+            s.wall_vertical[w] = spec->wall_vertical[w] ? 1 : 0; s.wall_hard[w] = spec->wall_hard[w] ? 1 : 0;
+            s.wall_axis_pos[w] = spec->wall_axis_pos[w]; s.wall_end0[w] = spec->wall_end0[w];
+            s.wall_end1[w] = spec->wall_end1[w]; s.wall_width[w] = spec->wall_width[w];
+        }
     }
     if (const char* why = check_structure(s)) {
         delete h;
@@ -165,7 +180,12 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
         DevTable t;
         memset(&t, 0, sizeof(t));
         for (int k = 0; k < A + L; ++k) { t.size[k] = s.size[k]; t.mass[k] = s.mass[k]; t.collide[k] = s.collide[k]; t.movable[k] = s.movable[k]; }
-        for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; }
+        for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; t.ghost[i] = s.ghost[i]; }
+        t.n_walls = s.n_walls;
+        for (int w = 0; w < s.n_walls; ++w) {
+            t.wall_vertical[w] = s.wall_vertical[w]; t.wall_hard[w] = s.wall_hard[w]; t.wall_axis_pos[w] = s.wall_axis_pos[w];
+            t.wall_end0[w] = s.wall_end0[w]; t.wall_end1[w] = s.wall_end1[w]; t.wall_width[w] = s.wall_width[w];
+        }
         if ((e = hipSetDevice(device)) != hipSuccess || (e = hipMalloc((void**)&h->table, sizeof(DevTable))) != hipSuccess ||
             (e = hipMemcpy(h->table, &t, sizeof(DevTable), hipMemcpyHostToDevice)) != hipSuccess) {
             if (h->table) (void)hipFree(h->table);

@@ -17,7 +17,10 @@ struct HostSpec {
     double size[MAX_E], mass[MAX_E];
     uint8_t movable[MAX_E], collide[MAX_E];
     double sens[MPE_MAX_AGENTS], max_speed[MPE_MAX_AGENTS];
-    uint8_t silent[MPE_MAX_AGENTS], adversary[MPE_MAX_AGENTS], leader[MPE_MAX_AGENTS];
+    uint8_t silent[MPE_MAX_AGENTS], adversary[MPE_MAX_AGENTS], leader[MPE_MAX_AGENTS], ghost[MPE_MAX_AGENTS];
+    int n_walls;
+    uint8_t wall_vertical[MPE_MAX_WALLS], wall_hard[MPE_MAX_WALLS];
+    double wall_axis_pos[MPE_MAX_WALLS], wall_end0[MPE_MAX_WALLS], wall_end1[MPE_MAX_WALLS], wall_width[MPE_MAX_WALLS];
     int E() const { return A + L; }
     bool any_speed_limit() const {
         for (int i = 0; i < A; ++i) if (isfinite(max_speed[i])) return true;
@@ -29,7 +32,10 @@ struct HostSpec {
 struct DevTable {
     double size[MAX_E], mass[MAX_E];
     double sens[MPE_MAX_AGENTS], max_speed[MPE_MAX_AGENTS];
-    uint8_t collide[MAX_E], movable[MAX_E], silent[MPE_MAX_AGENTS];
+    double wall_axis_pos[MPE_MAX_WALLS], wall_end0[MPE_MAX_WALLS], wall_end1[MPE_MAX_WALLS], wall_width[MPE_MAX_WALLS];
+    uint8_t collide[MAX_E], movable[MAX_E], silent[MPE_MAX_AGENTS], ghost[MPE_MAX_AGENTS];
+    uint8_t wall_vertical[MPE_MAX_WALLS], wall_hard[MPE_MAX_WALLS];
+    int n_walls;
 };
 
 // On-device Scenario.reset_world fused into the start of a rollout launch (mpe_episode).

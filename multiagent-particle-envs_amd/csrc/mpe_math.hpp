@@ -78,6 +78,34 @@ __device__ __forceinline__ V2<float> contact_force<float>(V2<float> pa, V2<float
     return f;
 }
 
+// World.get_wall_collision_force, multiagent/core.py:270-307.  Returns false when the wall exerts
+// no force (entity beyond the wall's ends, or a ghost agent at a soft wall).  float64 follows the
+// reference's operation order; float32 uses the same formulas in float.
+template <typename T>
+__device__ __forceinline__ bool wall_force(V2<T> p, T size, bool ghost, bool vertical, bool hard, T axis_pos, T end0, T end1, T width,
+                                           T cf, T k, V2<T>& out) {
+    if (ghost && !hard) return false;
+    const T prll = vertical ? p.y : p.x, perp = vertical ? p.x : p.y;
+    if (prll < end0 - size || prll > end1 + size) return false;
+    T theta = T(0), dist_min;
+    if (prll < end0 || prll > end1) {               // part of the entity is beyond the wall's end
+        const T past = (prll < end0) ? prll - end0 : prll - end1;
+        theta = (T)asin((double)(past / size));
+        dist_min = (T)cos((double)theta) * size + T(0.5) * width;
+    } else {
+        dist_min = size + T(0.5) * width;
+    }
+    const T delta = perp - axis_pos;
+    const T dist = t_abs<T>(delta);
+    const T pen = logaddexp0<T>(-(dist - dist_min) / k) * k;
+    const T mag = cf * delta / dist * pen;
+    const T f_perp = (T)cos((double)theta) * mag;
+    const T f_prll = (T)sin((double)theta) * t_abs<T>(mag);
+    out.x = vertical ? f_perp : f_prll;
+    out.y = vertical ? f_prll : f_perp;
+    return true;
+}
+
 // Scenario.is_collision: strict dist < size_1 + size_2 (simple_spread.py:77-81,
 // simple_tag.py:69-73, simple_world_comm.py:126-130).
 template <typename T> __device__ __forceinline__ bool touching(V2<T> p1, V2<T> p2, T dist_min) {

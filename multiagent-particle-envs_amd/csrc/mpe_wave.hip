@@ -115,6 +115,20 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                         f.y = g.y + f.y;
                     }
                 }
+                // ---- wall contact, after the entity contacts (core.py:182-188) ----
+                if (EPI == EPI_NONE) {
+                    const int n_walls = tb->n_walls;
+                    const bool my_ghost = tb->ghost[me] != 0;
+                    for (int w = 0; w < n_walls; ++w) {
+                        V2<T> wf;
+                        if (wall_force<T>(pi, my_size, my_ghost, tb->wall_vertical[w] != 0, tb->wall_hard[w] != 0, (T)tb->wall_axis_pos[w],
+                                          (T)tb->wall_end0[w], (T)tb->wall_end1[w], (T)tb->wall_width[w], p.contact_force,
+                                          p.contact_margin, wf)) {
+                            f.x = f.x + wf.x;
+                            f.y = f.y + wf.y;
+                        }
+                    }
+                }
                 integrate<T, CLAMP>(pi, vi, f, my_mass, my_max_speed, p.one_minus_damping, p.dt);   // core.py:193-204
             }
             __syncthreads();            // every lane has read the old positions

@@ -30,6 +30,10 @@ class WorldSpec:
     contact_force: float = 1e2
     contact_margin: float = 1e-3
     name: str = ""
+    # World.walls (multiagent/core.py:26-42) as dicts {orient 'H'|'V', axis_pos, endpoints (lo, hi), width, hard};
+    # Agent.ghost flags.  Only the physics-only step (SCN_NONE) simulates walls.
+    walls: list = field(default_factory=list)
+    ghost: np.ndarray = None
 
     def to_c(self):
         """Returns (MpeSpec, keepalive) -- keepalive owns the arrays the struct points into."""
@@ -39,8 +43,16 @@ class WorldSpec:
         arrs = dict(size=f64(self.size, E), mass=f64(self.mass, E), movable=u8(self.movable, E), collide=u8(self.collide, E),
                     sensitivity=f64(self.sensitivity, A), max_speed=f64(self.max_speed, A), silent=u8(self.silent, A),
                     adversary=u8(self.adversary, A), leader=u8(self.leader, A))
+        W = len(self.walls)
+        if W:
+            arrs.update(wall_vertical=u8([w["orient"] == "V" for w in self.walls], W), wall_axis_pos=f64([w["axis_pos"] for w in self.walls], W),
+                        wall_end0=f64([w["endpoints"][0] for w in self.walls], W), wall_end1=f64([w["endpoints"][1] for w in self.walls], W),
+                        wall_width=f64([w["width"] for w in self.walls], W), wall_hard=u8([w["hard"] for w in self.walls], W))
+        if self.ghost is not None:
+            arrs["ghost"] = u8(self.ghost, A)
         s = _lib.MpeSpec(scenario=self.scenario, n_agents=A, n_landmarks=self.n_landmarks, dim_c=self.dim_c,
-                         dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin)
+                         dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin,
+                         n_walls=W)
         for k, a in arrs.items():
             ptr_t = _lib._p_f64 if a.dtype == np.float64 else _lib._p_u8
             setattr(s, k, a.ctypes.data_as(ptr_t))
@@ -84,7 +96,7 @@ def world_comm_spec():
                      adversary=adv, leader=leader, name="simple_world_comm")
 
 
-def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, **world):
+def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, walls=(), ghost=None, **world):
     """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158); the
     scenario's observation / reward callbacks stay with the caller."""
     A, L = n_agents, n_landmarks
@@ -92,7 +104,7 @@ def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity,
                      movable=np.r_[np.ones(A, bool), np.zeros(L, bool)], collide=np.asarray(collide, bool),
                      sensitivity=np.asarray(sensitivity, float), max_speed=np.asarray(max_speed, float),
                      silent=np.asarray(silent, bool), adversary=np.zeros(A, bool), leader=np.zeros(A, bool),
-                     name="physics", **world)
+                     name="physics", walls=list(walls), ghost=None if ghost is None else np.asarray(ghost, bool), **world)
 
 
 def make_spec(name, **kw):

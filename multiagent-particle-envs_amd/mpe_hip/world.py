@@ -38,8 +38,7 @@ class Action:
 
 
 class Wall:
-    """Kept for attribute compatibility (multiagent/core.py:26-42).  Wall contact is not
-    simulated: a world with walls refuses to step."""
+    """Axis-aligned wall segment (multiagent/core.py:26-42); its contact force is part of the GPU step."""
 
     def __init__(self, orient="H", axis_pos=0.0, endpoints=(-1, 1), width=0.1, hard=True):
         self.orient, self.axis_pos, self.endpoints = orient, axis_pos, np.array(endpoints)
@@ -124,7 +123,8 @@ class World:
         ents = self.entities
         return (len(self.agents), len(self.landmarks), self.dim_c, self.dt, self.damping, self.contact_force, self.contact_margin,
                 tuple((e.size, e.mass, bool(e.movable), bool(e.collide)) for e in ents),
-                tuple((a.max_speed, bool(a.silent)) for a in self.agents), str(self.device))
+                tuple((a.max_speed, bool(a.silent), bool(getattr(a, "ghost", False))) for a in self.agents),
+                tuple((w.orient, w.axis_pos, tuple(w.endpoints), w.width, bool(w.hard)) for w in self.walls), str(self.device))
 
     def _physics_env(self):
         """One-world physics handle matching the entities' current static properties."""
@@ -134,13 +134,14 @@ class World:
         if self._phys is None or self._phys[0] != sig:
             A = len(self.agents)
             ents = self.entities
-            if self.walls:
-                raise NotImplementedError("worlds with walls are not simulated by the HIP kernels")
             spec = physics_spec(A, len(self.landmarks), self.dim_c,
                                 size=[e.size for e in ents], mass=[e.mass for e in ents], collide=[e.collide for e in ents],
                                 sensitivity=[a.accel if a.accel is not None else 5.0 for a in self.agents],
                                 max_speed=[a.max_speed if a.max_speed is not None else np.inf for a in self.agents],
                                 silent=[a.silent for a in self.agents],
+                                walls=[dict(orient=w.orient, axis_pos=w.axis_pos, endpoints=tuple(w.endpoints), width=w.width, hard=w.hard)
+                                       for w in self.walls],
+                                ghost=[getattr(a, "ghost", False) for a in self.agents],
                                 dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin)
             spec.movable = np.array([bool(e.movable) for e in ents])     # mpe_create refuses immovable agents / movable landmarks
             self._phys = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=self.device))

@@ -58,6 +58,9 @@ class Spec:
     # landmark roles for simple_world_comm (indices into the landmark list)
     food: List[int] = field(default_factory=list)
     forests: List[int] = field(default_factory=list)
+    # World.walls as dicts {orient, axis_pos, endpoints, width, hard} (core.py:26-42) and Agent.ghost
+    walls: List[dict] = field(default_factory=list)
+    ghost: Optional[np.ndarray] = None
 
     @property
     def E(self) -> int:
@@ -194,6 +197,31 @@ def collision_force(spec: Spec, pa, pb, size_a, size_b):
     return force
 
 
+def wall_force(spec: Spec, p, size, ghost, wall):
+    """World.get_wall_collision_force, multiagent/core.py:270-307, for positions p [B, 2].
+    Returns (force [B, 2], hit [B] bool); hit is None when the wall never acts (ghost at a soft wall)."""
+    if ghost and not wall["hard"]:
+        return None, None
+    prll_dim, perp_dim = (0, 1) if wall["orient"] == "H" else (1, 0)
+    e0, e1 = wall["endpoints"]
+    prll, perp = p[:, prll_dim], p[:, perp_dim]
+    hit = ~((prll < e0 - size) | (prll > e1 + size))
+    beyond = (prll < e0) | (prll > e1)
+    past = np.where(prll < e0, prll - e0, prll - e1)
+    with np.errstate(all="ignore"):
+        theta = np.where(beyond, np.arcsin(past / size), 0.0)
+        dist_min = np.where(beyond, np.cos(theta) * size + 0.5 * wall["width"], size + 0.5 * wall["width"])
+        delta = perp - wall["axis_pos"]
+        dist = np.abs(delta)
+        k = spec.contact_margin
+        pen = np.logaddexp(0, -(dist - dist_min) / k) * k
+        mag = spec.contact_force * delta / dist * pen
+        f = np.zeros_like(p)
+        f[:, perp_dim] = np.cos(theta) * mag
+        f[:, prll_dim] = np.sin(theta) * np.abs(mag)
+    return f, hit
+
+
 def world_step(spec: Spec, pos, vel, u, c):
     """One World.step.  Returns new (pos, vel, comm); inputs are not modified."""
     A, E = spec.A, spec.E
@@ -221,6 +249,17 @@ def world_step(spec: Spec, pos, vel, u, c):
                 if force[b] is None:
                     force[b] = np.zeros((B, 2))
                 force[b] = (-f) + force[b]              # core.py:181
+    # wall contact for every movable entity, after its entity contacts (core.py:182-188)
+    for i in range(A):
+        if not spec.movable[i]:
+            continue
+        for wall in spec.walls:
+            wf, hit = wall_force(spec, pos[:, i, :], spec.size[i], bool(spec.ghost[i]) if spec.ghost is not None else False, wall)
+            if hit is None:
+                continue
+            if force[i] is None:
+                force[i] = np.zeros((B, 2))
+            force[i] = np.where(hit[:, None], force[i] + wf, force[i])
     # integrate_state, core.py:193-204
     for i in range(A):
         if not spec.movable[i]:

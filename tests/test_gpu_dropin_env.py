@@ -149,8 +149,39 @@ def test_env_error_behaviour():
     from mpe_hip import scenarios
     with pytest.raises(FileNotFoundError):
         scenarios.load("no_such_scenario.py")
-    env.world.walls.append(object())
-    env2_world = env.world
-    with pytest.raises(NotImplementedError):
-        env2_world._phys = None
-        env2_world.step()
+
+
+def test_world_with_walls_steps_on_gpu():
+    """A user world with walls: World.step() applies the wall contact of core.py:270-307."""
+    from multiagent.core import World, Agent, Wall
+    from test_oracle_golden import walls_spec
+    g = load_golden("walls")
+    spec = walls_spec(g)
+    w = World()
+    w.dim_c = 2
+    for i in range(4):
+        a = Agent()
+        a.collide, a.silent, a.ghost = True, True, bool(spec.ghost[i])
+        a.size, a.accel, a.max_speed = (0.075, 3.0, 1.0) if i < 3 else (0.05, 4.0, 1.3)
+        w.agents.append(a)
+    from multiagent.core import Landmark
+    for _ in range(2):
+        lm = Landmark()
+        lm.collide, lm.movable, lm.size = True, False, 0.2
+        w.landmarks.append(lm)
+    w.walls = [Wall(orient=d["orient"], axis_pos=d["axis_pos"], endpoints=d["endpoints"], width=d["width"], hard=d["hard"])
+               for d in spec.walls]
+    b = 3
+    for i, e in enumerate(w.entities):
+        e.state.p_pos = g["pos0"][b, i].copy()
+        e.state.p_vel = g["vel0"][b, i].copy() if i < 4 else np.zeros(2)
+    for a in w.agents:
+        a.state.c = np.zeros(2)
+        a.action.c = np.zeros(2)
+    for t in range(25):
+        u, _ = orc.decode_actions(spec, g["actions"][t, b][None])
+        for i, a in enumerate(w.agents):
+            a.action.u = u[0, i].copy()
+        w.step()
+        assert _close([a.state.p_pos for a in w.agents], g["pos"][t, b]), t
+        assert _close([a.state.p_vel for a in w.agents], g["vel"][t, b]), t

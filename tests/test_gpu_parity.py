@@ -471,3 +471,38 @@ def test_far_outside_the_arena_boundary_penalty_saturates():
         obs, rew, done, _ = env.step(torch.as_tensor(act, dtype=torch.int32))
         assert _close(rew.cpu().numpy(), o_rew, tol, tol), (rew.cpu().numpy()[:, 3], o_rew[:, 3])
     assert o_rew[-1, 3] == -20.0 and o_rew[0, 3] == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_world_step_with_walls_matches_reference(dtype):
+    """mpe_world_step with wall contact against the trajectory captured from the reference's
+    World.step (walls with rounded ends, a soft wall and a ghost agent)."""
+    import mpe_hip
+    from test_oracle_golden import walls_spec
+    g = load_golden("walls")
+    spec = walls_spec(g)
+    dt = getattr(torch, dtype)
+    ps = mpe_hip.tag_spec()
+    phys = mpe_hip.physics_spec(ps.n_agents, ps.n_landmarks, ps.dim_c, ps.size, ps.mass, ps.collide, ps.sensitivity, ps.max_speed,
+                                ps.silent, walls=spec.walls, ghost=spec.ghost)
+    T, B, A = g["actions"].shape
+    env = mpe_hip.BatchedEnv(phys, B, dtype=dt)
+    if dtype == "float64":
+        env.set_state(g["pos0"], g["vel0"])
+        for t in range(T):
+            u, c = orc.decode_actions(spec, g["actions"][t])
+            env.world_step(u.reshape(B, -1))
+            pos, vel, _ = env.get_state()
+            assert _close(pos[:, :A], g["pos"][t], 1e-9, 1e-12), (t, np.abs(pos[:, :A] - g["pos"][t]).max())
+            assert _close(vel, g["vel"][t], 1e-9, 1e-12), t
+    else:
+        pos_prev, vel_prev = g["pos0"].copy(), g["vel0"]
+        for t in range(T):          # teacher-forced: wall contact is as stiff as entity contact
+            env.set_state(pos_prev, vel_prev)
+            u, c = orc.decode_actions(spec, g["actions"][t])
+            env.world_step(u.reshape(B, -1))
+            pos, vel, _ = env.get_state()
+            assert _close(pos[:, :A], g["pos"][t], 1e-4, 1e-4) and _close(vel, g["vel"][t], 1e-4, 2e-4), t
+            pos_prev = pos_prev.copy()
+            pos_prev[:, :A] = g["pos"][t]
+            vel_prev = g["vel"][t]

@@ -87,3 +87,23 @@ def test_reset_distribution_shapes():
         assert pos.shape == (3, spec.E, 2) and vel.shape == (3, spec.A, 2)
         lim = 1.0 if scn == "simple_spread" else 0.9
         assert np.abs(pos[:, spec.A:]).max() <= lim and np.abs(pos).max() <= 1.0
+
+
+def walls_spec(g):
+    """Oracle spec of the walled world of tests/golden/walls.npz (simple_tag-like entities)."""
+    spec = orc.spec_tag()
+    spec.walls = [dict(orient="V" if v else "H", axis_pos=float(a), endpoints=(float(e[0]), float(e[1])), width=float(w), hard=bool(h))
+                  for v, a, e, w, h in zip(g["wall_vertical"], g["wall_axis_pos"], g["wall_endpoints"], g["wall_width"], g["wall_hard"])]
+    spec.ghost = g["ghost"].astype(bool)
+    return spec
+
+
+def test_oracle_reproduces_reference_wall_contact():
+    """World.step with walls (core.py:182-188, 270-307), captured from the reference's own World.step."""
+    g = load_golden("walls")
+    spec = walls_spec(g)
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    for t in range(g["actions"].shape[0]):
+        u, c = orc.decode_actions(spec, g["actions"][t])
+        pos, vel, _ = orc.world_step(spec, pos, vel, u, c)
+        assert np.array_equal(pos[:, :4], g["pos"][t]) and np.array_equal(vel, g["vel"][t]), t

@@ -383,6 +383,62 @@ def init_spread64(rng, B=2):
 
 
 # ----------------------------------------------------------------------------
+def run_walls(ref):
+    """World.step with walls (core.py:182-188, 270-307): no in-scope scenario has walls, so a
+    simple_tag-like world is assembled from the reference classes with a box of walls (one soft,
+    one agent a ghost) and stepped through the reference's own World.step."""
+    core = ref.core
+    rng = np.random.RandomState(20240605)
+    B, A, L = 24, 4, 2
+    walls = [dict(orient="H", axis_pos=-1.0, endpoints=(-0.8, 0.8), width=0.1, hard=True),
+             dict(orient="H", axis_pos=1.0, endpoints=(-1.0, 1.0), width=0.2, hard=False),
+             dict(orient="V", axis_pos=-1.0, endpoints=(-1.0, 0.6), width=0.1, hard=True),
+             dict(orient="V", axis_pos=1.0, endpoints=(-0.5, 1.0), width=0.05, hard=True)]
+    world = core.World()
+    world.dim_c = 2
+    world.agents = [core.Agent() for _ in range(A)]
+    for i, a in enumerate(world.agents):
+        a.collide, a.silent = True, True
+        a.size, a.accel, a.max_speed = (0.075, 3.0, 1.0) if i < 3 else (0.05, 4.0, 1.3)
+        a.ghost = (i == 1)
+        a.action.c = np.zeros(2)
+    world.landmarks = [core.Landmark() for _ in range(L)]
+    for lm in world.landmarks:
+        lm.collide, lm.movable, lm.size = True, False, 0.2
+    world.walls = [core.Wall(orient=w["orient"], axis_pos=w["axis_pos"], endpoints=w["endpoints"], width=w["width"], hard=w["hard"])
+                   for w in walls]
+    pos0 = np.concatenate([rng.uniform(-1, 1, (B, A, 2)), rng.uniform(-0.6, 0.6, (B, L, 2))], axis=1)
+    vel0 = rng.uniform(-0.5, 0.5, (B, A, 2))
+    # agents pressed against / just past the ends of each wall
+    for b in range(8):
+        w = walls[b % 4]
+        along = [w["endpoints"][0] - 0.05, w["endpoints"][1] + 0.04, 0.5 * sum(w["endpoints"]), w["endpoints"][1] - 0.01][b // 2 % 4]
+        off = w["axis_pos"] + (0.06 if b % 2 else -0.06)
+        for i in range(A):
+            pos0[b, i] = (along + 0.017 * i, off) if w["orient"] == "H" else (off, along + 0.017 * i)
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+    rec = {"pos": np.zeros((T_STEPS, B, A, 2)), "vel": np.zeros((T_STEPS, B, A, 2))}
+    for b in range(B):
+        inject(world, pos0[b], vel0[b])
+        for t in range(T_STEPS):
+            for i, a in enumerate(world.agents):
+                u = np.zeros(2)
+                m = int(actions[t, b, i])
+                if m == 1: u[0] = -1.0
+                if m == 2: u[0] = +1.0
+                if m == 3: u[1] = -1.0
+                if m == 4: u[1] = +1.0
+                a.action.u = u * a.accel
+            world.step()
+            rec["pos"][t, b] = [a.state.p_pos for a in world.agents]
+            rec["vel"][t, b] = [a.state.p_vel for a in world.agents]
+    rec.update(pos0=pos0, vel0=vel0, actions=actions.astype(np.int32),
+               wall_vertical=np.array([w["orient"] == "V" for w in walls]), wall_axis_pos=np.array([w["axis_pos"] for w in walls]),
+               wall_endpoints=np.array([w["endpoints"] for w in walls]), wall_width=np.array([w["width"] for w in walls]),
+               wall_hard=np.array([w["hard"] for w in walls]), ghost=np.array([a.ghost for a in world.agents]))
+    return rec
+
+
 def known_answers(ref):
     """Anchors that do not use state injection."""
     out = {}
@@ -459,6 +515,9 @@ def main():
         np.savez_compressed(path, scenario=np.array(scn), pos0=pos0, vel0=vel0,
                             actions=actions.astype(np.int32), **rec)
         print("wrote", path, os.path.getsize(path), "bytes")
+    walls = run_walls(ref)
+    np.savez_compressed(os.path.join(OUT, "walls.npz"), **walls)
+    print("wrote walls.npz")
     kat = known_answers(ref)
     np.savez_compressed(os.path.join(OUT, "kat.npz"), **kat)
     print("wrote kat.npz")
