@@ -19,8 +19,8 @@ Launch modes (--mode):
 
 Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   roofline      HBM roofline of the dominant kernel; achieved = algorithmic bytes per launch /
-                average launch duration from HIP events bracketing launches of the timed region
-                (every 4th launch by default, see --event-every)
+                average launch duration from HIP event pairs inside the timed region, each
+                bracketing 4 consecutive launches (every 4th group by default, --event-every)
   cpu_baseline  the single-env numpy oracle (oracle/mpe_oracle.py) timed on this host, 1 core
   step_mode     the same workload issued as one mpe_step launch per step (hipGraph), for comparison
 """
@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "multiagent-particle-envs_amd"))
 
 EPISODE = 25
+EVENT_GROUP = 4               # launches bracketed by one HIP event pair in rollout mode
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 
 # Algorithmic bytes per env-step, float32 (s = 4), int32 actions, 1-byte done.
@@ -41,8 +42,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 #                   writes agent pos+vel 4A*s, obs obs_total*s, rewards A*s, done 1
 #   rollout launch: state is read once and written once per launch of EPISODE steps, so per
 #                   env-step only actions are read and obs, rewards, done written.
-def algorithmic_bytes(A, L, n_act, obs_total, s, steps_per_launch):
-    state_rd = 4 * A * s + 2 * L * s
+#   episode launch: as rollout, but the initial state is drawn on the device, not read.
+def algorithmic_bytes(A, L, n_act, obs_total, s, steps_per_launch, reads_state=True):
+    state_rd = (4 * A * s + 2 * L * s) if reads_state else 0
     state_wr = 4 * A * s
     per_step = 4 * n_act + obs_total * s + A * s + 1
     return per_step + (state_rd + state_wr) / float(steps_per_launch)
@@ -91,8 +93,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-mode", action="store_true")
     ap.add_argument("--event-every", type=int, default=4,
-                    help="bracket every k-th episode launch with HIP events (markers around every launch cost ~7 us each "
-                         "and would throttle submission; the sampled average agrees with rocprofv3's per-kernel average)")
+                    help="time every k-th group of 4 episode launches with one HIP event pair (a pair costs ~7 us on the "
+                         "stream, so pairs around every launch would throttle submission and inflate the average)")
     args = ap.parse_args()
 
     import torch
@@ -150,21 +152,28 @@ def main():
         """n_steps env steps in episodes of EPISODE; returns the number of dominant-kernel launches."""
         nonlocal out
         done_steps, launches, ep = 0, 0, 0
+        open_pair = None
         while done_steps < n_steps:
             n = min(EPISODE, n_steps - done_steps)
             if mode != "rollout":
                 env.reset(seed=1234 + first_env)
             if mode == "rollout":
-                rec = record and (launches % args.event_every == 0)
-                if rec:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                # one event pair brackets EVENT_GROUP consecutive launches (an event pair costs
+                # about 7 us on the stream, a tenth of one launch), every event_every-th group
+                grp = launches // EVENT_GROUP
+                rec = record and n == EPISODE and (grp % args.event_every == 0)
+                if rec and launches % EVENT_GROUP == 0:
+                    e0 = torch.cuda.Event(enable_timing=True)
                     e0.record()
+                    open_pair = e0
                 # mpe_episode: on-device reset of every env + n steps in one launch
                 out = env.rollout(actions[:n], out if (out is not None and out["obs"].shape[0] == n) else None,
                                   reset_seed=1234 + first_env)
-                if rec:
+                if rec and launches % EVENT_GROUP == EVENT_GROUP - 1 and open_pair is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
-                    pairs.append((e0, e1, n))
+                    pairs.append((open_pair, e1, n * EVENT_GROUP))
+                    open_pair = None
                 launches += 1
             elif mode == "graph" and n == EPISODE:
                 g = episode_graph()
@@ -215,13 +224,13 @@ def main():
     # holds EPISODE single-step launches, so its time is divided by the steps it ran)
     tot_ms = sum(a.elapsed_time(b) for a, b, _ in pairs)
     if args.mode == "rollout":
-        kern_ms, avg_steps = tot_ms / max(1, len(pairs)), sum(n for _, _, n in pairs) / max(1, len(pairs))
+        kern_ms, avg_steps = tot_ms / max(1, len(pairs) * EVENT_GROUP), float(EPISODE)
     else:
         kern_ms, avg_steps = tot_ms / max(1, sum(n for _, _, n in pairs)), 1.0
 
     s = 4 if args.dtype == "f32" else 8
     lo = env.layout
-    bytes_env_step = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, steps_per_launch)
+    bytes_env_step = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, steps_per_launch, reads_state=args.mode != "rollout")
     bytes_launch = bytes_env_step * B * avg_steps
     achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
 
