@@ -7,3 +7,10 @@ hipError_t launch_small_f32(const HostSpec& s, long long B, int mode, const Step
 }
 }  // namespace mpe
 
+
+#ifdef MPE_STAMPS
+// Diagnostic build only: copy the per-workgroup timestamps to host memory.
+extern "C" int mpe_debug_stamps(long long* host, long long count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mpe::g_stamps), (size_t)count * sizeof(long long));
+}
+#endif

@@ -64,6 +64,15 @@ struct Tile {
     }
 };
 
+#ifdef MPE_STAMPS
+// Diagnostic build only: 100 MHz timestamps per workgroup (slot 0 start, 1 state and actions ready,
+// 2+t step t computed and its rows issued, 60 all steps done).  tools/probes/episode_stamps.py reads them.
+__device__ long long g_stamps[4096 * 64];
+#define STAMP(slot) do { if (lane == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 // EPW: envs per wave (tile rows); 64 uses every lane.
 // FULL: every wave of the launch owns EPW valid envs and all output blocks are 16-byte aligned.
 // INFO: info_i / info_f are written.  env_begin / env_end: the env range this launch covers.
@@ -86,8 +95,8 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     using IfTile = Tile<T, NF, true, EPW>;
     __shared__ __attribute__((aligned(16))) T tile_obs[ObsTile::SIZE];
     __shared__ __attribute__((aligned(16))) T tile_rew[RewTile::SIZE];
-    __shared__ __attribute__((aligned(16))) int tile_ii[IiTile::SIZE];
-    __shared__ __attribute__((aligned(16))) T tile_if[IfTile::SIZE];
+    __shared__ __attribute__((aligned(16))) int tile_ii[INFO ? IiTile::SIZE : 4];
+    __shared__ __attribute__((aligned(16))) T tile_if[INFO ? IfTile::SIZE : 4];
 
     const int lane = threadIdx.x;
     const long long B = p.n_envs;
@@ -98,6 +107,59 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     const int tile_lane = (EPW == 64 || lane < EPW) ? lane : 0;   // lanes beyond the tile write row 0 (masked below)
     const long long b = valid ? env0 + lane : env0;   // idle tail lanes shadow the wave's first env
 
+    STAMP(0);
+    // Actions are fetched NP * CH steps at a time and packed 3 bits each into NP 128-bit shift
+    // registers, so the step loop itself issues no loads: memory operations retire in issue order,
+    // and a load issued between two steps' store bursts is only served after every older store has
+    // drained (about 4 us in mid-launch).  NP is as many registers as the usual 25-step episode needs,
+    // within a budget of 84 loaded words held at once (more costs occupancy in large batches).  The
+    // first fetch is issued before the state is set up, so that its latency overlaps the reset
+    // draws, and all loads of a fetch are issued before any is consumed.  Move ints outside 0..7 are
+    // no-ops like any value outside 1..4 (environment.py:178-181); a comm int outside 0..7 selects
+    // no word.
+    constexpr int ABITS = 3 * NA;
+    constexpr int CH = (MODE == MODE_ROLLOUT) ? (128 / ABITS) : 1;
+    constexpr int NP_EPISODE = (25 + CH - 1) / CH, NP_BUDGET = 84 / (CH * NA) > 0 ? 84 / (CH * NA) : 1;
+    constexpr int NP = (MODE == MODE_ROLLOUT) ? (NP_EPISODE < NP_BUDGET ? NP_EPISODE : NP_BUDGET) : 1;
+    static_assert(ABITS <= 64, "one step's actions must fit 64 bits");
+    unsigned __int128 fetched[NP] = {};
+    unsigned raw[NP * CH][NA];
+    auto load_actions = [&](int t0) {
+#pragma unroll
+        for (int k = 0; k < NP * CH; ++k) {
+            const long long tt = (t0 + k < n_steps) ? t0 + k : n_steps - 1;     // past the end: re-read the last step
+#pragma unroll
+            for (int j = 0; j < NA; ++j) raw[k][j] = (unsigned)actions[(tt * B + b) * NA + j];
+        }
+    };
+    auto pack_actions = [&]() {
+        // pin the first use of the loaded words here, so that nothing waits on them earlier
+#pragma unroll
+        for (int k = 0; k < NP * CH; ++k) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) asm volatile("" : "+v"(raw[k][j]));
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            fetched[q] = 0;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                int col = 0;
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    const unsigned mv = raw[q * CH + k][col];
+                    fetched[q] |= (unsigned __int128)(mv < 7u ? mv : 7u) << (k * ABITS + 3 * col);     // 5, 6, 7: no move
+                    ++col;
+                    if (Cfg::speaks(i)) {
+                        const unsigned wd = raw[q * CH + k][col];
+                        fetched[q] |= (unsigned __int128)(wd < 7u ? wd : 7u) << (k * ABITS + 3 * col);
+                        ++col;
+                    }
+                }
+            }
+        }
+    };
+    if (MODE != MODE_OBSERVE && n_steps > 0) load_actions(0);
     V2<T> pos[E];
     V2<T> vel[A];
     T comm[DC > 0 ? DC : 1];
@@ -135,38 +197,22 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     }
     constexpr bool want_info = INFO;
 
-    // Actions are fetched a chunk of CH steps at a time and packed 3 bits each into a 128-bit shift
-    // register, so the step loop itself issues no loads: memory operations retire in issue order,
-    // and a load issued between two steps' store bursts could only be consumed after every older
-    // store had drained.  Move ints outside 0..7 are no-ops like any value outside 1..4
-    // (environment.py:178-181); a comm int outside 0..7 selects no word.
-    constexpr int ABITS = 3 * NA;
-    constexpr int CH = (MODE == MODE_ROLLOUT) ? (128 / ABITS) : 1;
-    static_assert(ABITS <= 64, "one step's actions must fit 64 bits");
-
-    for (int t0 = 0; t0 < n_steps; t0 += CH) {
-      unsigned __int128 packed = 0;
+    for (int t0 = 0; t0 < n_steps; t0 += NP * CH) {
       if (MODE != MODE_OBSERVE) {
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const long long tt = (t0 + k < n_steps) ? t0 + k : n_steps - 1;
-            int col = 0;
-#pragma unroll
-            for (int i = 0; i < A; ++i) {
-                const unsigned mv = (unsigned)actions[(tt * B + b) * NA + col];
-                packed |= (unsigned __int128)(mv > 7u ? 0u : mv) << (k * ABITS + 3 * col);
-                ++col;
-                if (Cfg::speaks(i)) {
-                    const unsigned wd = (unsigned)actions[(tt * B + b) * NA + col];
-                    packed |= (unsigned __int128)(wd > 7u ? 7u : wd) << (k * ABITS + 3 * col);
-                    ++col;
-                }
-            }
-        }
+          if (t0 > 0) load_actions(t0);
+          pack_actions();
       }
-      const int nc = (n_steps - t0 < CH) ? n_steps - t0 : CH;
+      const int nc = (n_steps - t0 < NP * CH) ? n_steps - t0 : NP * CH;
+      if (t0 == 0) STAMP(1);
+      unsigned __int128 packed = 0;
       for (int kc = 0; kc < nc; ++kc) {
         const int t = t0 + kc;
+        if (kc % CH == 0) {          // next shift register (uniform select, NP is small)
+            const int q = kc / CH;
+            packed = fetched[0];
+#pragma unroll
+            for (int j = 1; j < NP; ++j) if (q == j) packed = fetched[j];
+        }
         if (MODE != MODE_OBSERVE) {
             const unsigned long long cur = (unsigned long long)packed;
             packed >>= ABITS;
@@ -264,10 +310,14 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::template flush<FULL>(tile_if, info_f_g + row0 * NF, lane, nvalid);
             }
         }
-        if (MODE == MODE_ROLLOUT) __syncthreads();   // tiles are rewritten by the next step
+        if (MODE == MODE_ROLLOUT) {
+            if (t < 28) STAMP(2 + t);
+            __syncthreads();   // tiles are rewritten by the next step
+        }
       }
     }
 
+    STAMP(60);
     if (MODE != MODE_OBSERVE && valid) {
 #pragma unroll
         for (int i = 0; i < A; ++i) {
@@ -318,9 +368,15 @@ static void launch_epw(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, con
     launch_range<T, Cfg, CLAMP, MODE, false, INFO, 64>(p, n_full, B, a, st);
 }
 
-// Every launch uses 64-env tiles: 32- and 16-env tiles were measured at 65 536 and 262 144 envs and
-// lose 15 % / 50 % (a wave's instruction stream is as long whatever its tile, so narrower tiles only
-// multiply the instructions issued).
+// Every launch uses 64-env tiles and one-wave workgroups.  Measured alternatives at 65 536 envs
+// (one wave per SIMD): 32- / 16-env tiles lose 15 % / 50 % (a wave's instruction stream is as long
+// whatever its tile, so narrower tiles only multiply the instructions issued); a two-wave workgroup
+// whose second wave does nothing but stream finished tiles out of a double-buffered LDS tile, and
+// issuing step t-1's stores in slices between the phases of step t, both change nothing: per-wave
+// timestamps show every wave store-bound from step 2 on (1.4-2.8 us per step against 0.9 us of
+// arithmetic), i.e. the launch is limited by how fast the fabric takes the rows, not by a wave
+// stalling on its own burst.  Weighting the tiles per XCD (odd XCDs finish 15-20 % later) only moved
+// the slow spot to other XCDs.
 template <typename T, class Cfg, bool CLAMP, int MODE, bool INFO>
 static void launch_mode(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, const StepArgs& a, hipStream_t st) {
     launch_epw<T, Cfg, CLAMP, MODE, INFO, 64>(p, B, a, st);
