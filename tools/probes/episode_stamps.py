@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-workgroup timeline of one mpe_episode launch.
 
-Needs a library built with -DMPE_STAMPS (see tools/probes/README) named by MPE_HIP_LIB.
+Needs a library built with -DMPE_STAMPS (see README.md next to this file) named by MPE_HIP_LIB.
 Prints, over all workgroups, when (us after the earliest workgroup start) each wave had computed a
 step and issued its stores, and the spread of wave lifetimes by XCD.
 """
