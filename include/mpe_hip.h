@@ -11,8 +11,9 @@
  *     thrown across the boundary.  mpe_last_error() returns a description of the last failure
  *     on a handle (or of the last failed mpe_create when called with NULL).
  *   - The caller allocates and owns every buffer.  All data pointers are DEVICE pointers on the
- *     handle's device.  The library only holds the immutable world description and a small
- *     per-entity table in device memory.
+ *     handle's device and 16-byte aligned (rows leave the kernels as 16-byte vectors; a misaligned
+ *     pointer is refused with MPE_ERR_INVALID).  The library only holds the immutable world
+ *     description and a small per-entity table in device memory.
  *   - Kernels are enqueued on the caller's stream and the call returns without synchronising.
  *   - A handle is not thread-safe; distinct handles are independent.  There is no global state.
  *
@@ -21,6 +22,9 @@
  *   pos      T[2E][B]        row 2e+d holds coordinate d of entity e for every env (env-minor)
  *   vel      T[2A][B]        same for agent velocities (landmarks never move)
  *   comm     T[S*dim_c][B]   state.c of the S non-silent agents, in agent order (may be NULL if S == 0)
+ *   aux      int32[n_aux][B] what reset_world draws besides positions and keeps for the episode:
+ *                            row 0 is the index of the goal landmark (agent.goal_a) in
+ *                            simple_adversary and simple_push (may be NULL if n_aux == 0)
  *     Small worlds (one lane simulates one world) keep this env-minor layout so that a wave's 64
  *     worlds load as coalesced rows.  Worlds simulated by a whole wave (MpeLayout.state_env_major
  *     == 1: simple_spread other than 3/3, and MPE_SCN_NONE) store the state arrays transposed,
@@ -57,6 +61,9 @@ extern "C" {
 #define MPE_SCN_SPREAD 1     /* multiagent/scenarios/simple_spread.py */
 #define MPE_SCN_TAG 2        /* multiagent/scenarios/simple_tag.py */
 #define MPE_SCN_WORLD_COMM 3 /* multiagent/scenarios/simple_world_comm.py */
+#define MPE_SCN_SIMPLE 4     /* multiagent/scenarios/simple.py */
+#define MPE_SCN_ADVERSARY 5  /* multiagent/scenarios/simple_adversary.py */
+#define MPE_SCN_PUSH 6       /* multiagent/scenarios/simple_push.py */
 
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_LANDMARKS 64
@@ -110,10 +117,15 @@ typedef struct MpeLayout {
                             simple_tag: A collision counts;
                             simple_world_comm: A collision counts + in_forest bits (bit 2i+f)
                             + visibility bits (agent i sees its k-th other agent, others in
-                            ascending order skipping i: bit (A-1)*i+k) */
-    int32_t n_info_f;    /* simple_spread: min_dists + A benchmark rewards; otherwise 0 */
+                            ascending order skipping i: bit (A-1)*i+k);
+                            simple_adversary: the goal landmark index;
+                            simple, simple_push: none (no benchmark_data), info_i must be NULL */
+    int32_t n_info_f;    /* simple_spread: min_dists + A benchmark rewards;
+                            simple_adversary: benchmark_data (simple_adversary.py:56-65) flattened in
+                            agent order: the adversary's squared goal distance, then per good agent
+                            its squared distance to each landmark and to the goal; otherwise 0 */
     int32_t state_env_major; /* 0: pos/vel/comm are [rows][B]; 1: [B][rows] (see "Memory layout") */
-    int32_t reserved;
+    int32_t n_aux;       /* rows of aux */
     int32_t obs_dim[MPE_MAX_AGENTS];
     int32_t obs_offset[MPE_MAX_AGENTS];
 } MpeLayout;
@@ -133,10 +145,10 @@ const char* mpe_last_error(const MpeHandle* h);
  *   World.step (core.py:142-158: apply_action_force :161-167, apply_environment_force :170-181 with
  *   get_collision_force :215-233, integrate_state :193-204, update_agent_state :206-212) ->
  *   the scenario's observation / reward / benchmark_data callbacks.
- * pos, vel and comm are updated in place.
+ * pos, vel and comm are updated in place; aux is read (mpe_step_auto rewrites it when it resets).
  */
-int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
-             void* rew, uint8_t* done, int32_t* info_i, void* info_f, mpe_stream_t stream);
+int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux,
+             void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f, mpe_stream_t stream);
 
 /*
  * mpe_step plus the episode bookkeeping the reference leaves to its caller (the runner loop of
@@ -149,8 +161,8 @@ int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* c
  * (rew and info still describe the step that ended the old one).  All four bookkeeping arrays are
  * caller-owned device buffers, zero-initialised by the caller before the first episode.
  */
-int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
-                  void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t* step_count,
+int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux,
+                  void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t* step_count,
                   int32_t* episode_count, void* ep_return, void* last_return, int32_t max_steps,
                   uint64_t seed, mpe_stream_t stream);
 
@@ -161,8 +173,8 @@ int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, vo
  * done uint8[n_steps][B], info_* likewise.  pos/vel/comm hold the state before the first step on
  * entry and after the last on return.
  */
-int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
-                void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps,
+int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux,
+                void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps,
                 mpe_stream_t stream);
 
 /*
@@ -173,24 +185,27 @@ int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void
  * mpe_rollout when the policy needs it).
  */
 int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos,
-                void* vel, void* comm, void* obs, void* rew, uint8_t* done, int32_t* info_i,
+                void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done, int32_t* info_i,
                 void* info_f, int32_t n_steps, mpe_stream_t stream);
 
 /* The scenario callbacks on the current state, without stepping: observation for every agent
  * (what MultiAgentEnv.reset returns, environment.py:122-127) and, when rew is not NULL, also
  * reward (environment.py:149-152) and benchmark_data (info_i / info_f, NULL to skip). */
-int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs, void* rew,
+int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, const int32_t* aux,
+                void* obs, void* rew,
                 int32_t* info_i, void* info_f, mpe_stream_t stream);
 
 /*
  * Scenario.reset_world (simple_spread.py:40-56, simple_tag.py:39-54, simple_world_comm.py:88-113)
  * for every env whose mask byte is non-zero (all envs when mask is NULL): agent positions
- * U(-1,1)^2, landmark positions U(-1,1)^2 (simple_spread) or U(-0.9,0.9)^2, zero velocity and comm.
+ * U(-1,1)^2, landmark positions U(-1,1)^2 (simple_spread, simple, simple_adversary, simple_push) or
+ * U(-0.9,0.9)^2, zero velocity and comm; the goal landmark of simple_adversary (:41-45) and
+ * simple_push (:40-42) uniform over the landmarks.
  * Draws come from a counter-based generator keyed by (seed, env index, episode); they follow the
  * reference's distributions, not numpy's Mersenne-Twister stream.
  */
 int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask, void* pos,
-              void* vel, void* comm, mpe_stream_t stream);
+              void* vel, void* comm, int32_t* aux, mpe_stream_t stream);
 
 /*
  * World.step alone (core.py:142-158) for scenarios whose callbacks stay in Python (handles created

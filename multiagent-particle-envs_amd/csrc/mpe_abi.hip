@@ -68,6 +68,24 @@ static const char* check_structure(const HostSpec& s) {
             for (int l = 0; l < L; ++l)
                 if (s.collide[A + l] != (l == 0)) return "simple_world_comm: only the first landmark collides";
             return nullptr;
+        case MPE_SCN_SIMPLE:
+            if (A != 1 || L != 1) return "simple has 1 agent and 1 landmark";
+            if (s.collide[0] || s.collide[1] || !s.silent[0]) return "simple: nothing collides, the agent is silent";
+            return nullptr;
+        case MPE_SCN_ADVERSARY:
+            if (A != 3 || L != 2) return "simple_adversary has 3 agents and 2 landmarks";
+            for (int e = 0; e < A + L; ++e)
+                if (s.collide[e]) return "simple_adversary: nothing collides";
+            for (int i = 0; i < A; ++i)
+                if (!s.silent[i] || s.adversary[i] != (i < 1)) return "simple_adversary agents are silent, agent 0 is the adversary";
+            return nullptr;
+        case MPE_SCN_PUSH:
+            if (A != 2 || L != 2) return "simple_push has 2 agents and 2 landmarks";
+            for (int i = 0; i < A; ++i)
+                if (!s.collide[i] || !s.silent[i] || s.adversary[i] != (i < 1)) return "simple_push agents collide and are silent, agent 0 is the adversary";
+            for (int l = 0; l < L; ++l)
+                if (s.collide[A + l]) return "simple_push landmarks do not collide";
+            return nullptr;
     }
     return "unknown scenario id";
 }
@@ -94,6 +112,9 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
             case MPE_SCN_SPREAD: d = 4 + 2 * L + 2 * (A - 1); break;
             case MPE_SCN_TAG: d = 4 + 2 * L + 2 * (A - 1) + 2 * good_others; break;
             case MPE_SCN_WORLD_COMM: d = 4 + 2 * L + 2 * (A - 1) + 2 * good_others + 2 + (s.adversary[i] ? s.dim_c : 0); break;
+            case MPE_SCN_SIMPLE: d = 2 + 2 * L; break;
+            case MPE_SCN_ADVERSARY: d = (s.adversary[i] ? 0 : 2) + 2 * L + 2 * (A - 1); break;
+            case MPE_SCN_PUSH: d = s.adversary[i] ? 2 + 2 * L + 2 * (A - 1) : 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1); break;
             default: d = 0;
         }
         lo->obs_dim[i] = d;
@@ -105,8 +126,10 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
         case MPE_SCN_SPREAD: lo->n_info_i = A + 1; lo->n_info_f = A + 1; break;
         case MPE_SCN_TAG: lo->n_info_i = A; break;
         case MPE_SCN_WORLD_COMM: lo->n_info_i = A + 2; break;
+        case MPE_SCN_ADVERSARY: lo->n_info_i = 1; lo->n_info_f = 1 + (A - 1) * (L + 1); break;
         default: break;
     }
+    lo->n_aux = s.n_aux();
 }
 
 extern "C" {
@@ -222,6 +245,12 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
     if (mode != 2 && (!a.actions || !a.rew || !a.done)) return fail(h, MPE_ERR_INVALID, "%s: actions, rew and done must not be NULL", who);
     if (mode == 1 && a.n_steps < 1) return fail(h, MPE_ERR_INVALID, "%s: n_steps must be >= 1", who);
     if (a.info_f && !a.info_i) return fail(h, MPE_ERR_INVALID, "%s: info_f requires info_i", who);
+    if (a.info_i && h->layout.n_info_i == 0) return fail(h, MPE_ERR_INVALID, "%s: this scenario has no benchmark_data; info_i must be NULL", who);
+    if (h->layout.n_aux > 0 && !a.aux) return fail(h, MPE_ERR_INVALID, "%s: aux must not be NULL for a scenario with a goal landmark", who);
+    // rows leave the kernels as 16-byte vectors
+    const void* bufs[] = {a.pos, a.vel, a.comm, a.obs, a.rew, a.info_i, a.info_f, a.actions, a.aux};
+    for (const void* ptr : bufs)
+        if (((uintptr_t)ptr & 15u) != 0) return fail(h, MPE_ERR_INVALID, "%s: every buffer must be 16-byte aligned (got %p)", who, ptr);
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
     e = h->use_wave ? launch_wave(h->spec, h->table, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream)
@@ -230,13 +259,14 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
     return MPE_OK;
 }
 
-int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs, void* rew,
+int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew,
              uint8_t* done, int32_t* info_i, void* info_f, mpe_stream_t stream) {
-    const StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, 1};
+    StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, 1};
+    a.aux = aux;
     return run(h, 0, a, stream, "mpe_step");
 }
 
-int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs, void* rew, uint8_t* done,
+int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done,
                   int32_t* info_i, void* info_f, int32_t* step_count, int32_t* episode_count, void* ep_return, void* last_return,
                   int32_t max_steps, uint64_t seed, mpe_stream_t stream) {
     if (!h) return MPE_ERR_INVALID;
@@ -245,38 +275,43 @@ int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, vo
     if (max_steps < 1) return fail(h, MPE_ERR_INVALID, "mpe_step_auto: max_steps must be >= 1");
     StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, 1};
     a.au = AutoArgs{step_count, episode_count, ep_return, last_return, max_steps, seed, landmark_limit(h->spec)};
+    a.aux = aux;
     return run(h, 0, a, stream, "mpe_step_auto");
 }
 
-int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, void* obs, void* rew,
+int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew,
                 uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps, mpe_stream_t stream) {
-    const StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_steps};
+    StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_steps};
+    a.aux = aux;
     return run(h, 1, a, stream, "mpe_rollout");
 }
 
-int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos, void* vel, void* comm, void* obs,
-                void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps, mpe_stream_t stream) {
+int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux,
+                void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps, mpe_stream_t stream) {
     StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_steps};
+    a.aux = aux;
     if (h) a.reset = ResetArgs{1, seed, episode, landmark_limit(h->spec)};
     return run(h, 1, a, stream, "mpe_episode");
 }
 
-int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, void* obs, void* rew, int32_t* info_i,
-                void* info_f, mpe_stream_t stream) {
+int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, const int32_t* aux, void* obs, void* rew,
+                int32_t* info_i, void* info_f, mpe_stream_t stream) {
     if (h && !rew && (info_i || info_f)) return fail(h, MPE_ERR_INVALID, "mpe_observe: info_i / info_f require rew");
-    const StepArgs a{nullptr, (void*)pos, (void*)vel, (void*)comm, obs, rew, nullptr, info_i, info_f, 1};
+    StepArgs a{nullptr, (void*)pos, (void*)vel, (void*)comm, obs, rew, nullptr, info_i, info_f, 1};
+    a.aux = (int32_t*)aux;
     return run(h, 2, a, stream, "mpe_observe");
 }
 
 int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask, void* pos, void* vel, void* comm,
-              mpe_stream_t stream) {
+              int32_t* aux, mpe_stream_t stream) {
     if (!h) return MPE_ERR_INVALID;
     if (!pos || !vel) return fail(h, MPE_ERR_INVALID, "mpe_reset: pos and vel must not be NULL");
     const int comm_rows = h->layout.n_speakers * h->spec.dim_c;
     if (comm_rows > 0 && !comm) return fail(h, MPE_ERR_INVALID, "mpe_reset: comm must not be NULL for a scenario with speaking agents");
+    if (h->layout.n_aux > 0 && !aux) return fail(h, MPE_ERR_INVALID, "mpe_reset: aux must not be NULL for a scenario with a goal landmark");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
-    e = launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, h->use_wave, seed, episode, mask, pos, vel, comm, (hipStream_t)stream);
+    e = launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, h->use_wave, seed, episode, mask, pos, vel, comm, aux, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, "mpe_reset");
     return MPE_OK;
 }

@@ -22,6 +22,8 @@ struct HostSpec {
     uint8_t wall_vertical[MPE_MAX_WALLS], wall_hard[MPE_MAX_WALLS];
     double wall_axis_pos[MPE_MAX_WALLS], wall_end0[MPE_MAX_WALLS], wall_end1[MPE_MAX_WALLS], wall_width[MPE_MAX_WALLS];
     int E() const { return A + L; }
+    // rows of per-episode scenario state: the goal landmark index of simple_adversary / simple_push
+    int n_aux() const { return (scenario == MPE_SCN_ADVERSARY || scenario == MPE_SCN_PUSH) ? 1 : 0; }
     bool any_speed_limit() const {
         for (int i = 0; i < A; ++i) if (isfinite(max_speed[i])) return true;
         return false;
@@ -65,6 +67,7 @@ struct StepArgs {
     int n_steps;
     ResetArgs reset;
     AutoArgs au;
+    int32_t* aux;             // [n_aux][B] per-episode scenario state (goal landmark index), or NULL
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112
@@ -80,7 +83,7 @@ hipError_t launch_small(const HostSpec& s, long long n_envs, int dtype, int mode
 namespace mpe {
 // on-device reset_world (mpe_reset.hip); env_major selects the state layout
 hipError_t launch_reset(const HostSpec& s, long long n_envs, int dtype, int comm_rows, bool env_major, unsigned long long seed,
-                        unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, hipStream_t st);
+                        unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, int32_t* aux, hipStream_t st);
 
 // wave-per-world kernels (mpe_wave.hip), env-major state; mode: 0 step, 1 rollout, 2 observe
 bool wave_supported(const HostSpec& s);

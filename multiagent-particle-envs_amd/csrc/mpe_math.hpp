@@ -214,4 +214,14 @@ __host__ __device__ inline V2<double> reset_draw(const RS& rs, unsigned long lon
     return d;
 }
 
+// Index of the goal landmark (np.random.choice(world.landmarks), simple_adversary.py:42,
+// simple_push.py:41) of world `b` in episode rs.episode: uniform over n_landmarks, from the Philox
+// block with counter (b, episode * 256 + 255), which no entity uses.
+template <class RS>
+__host__ __device__ inline int reset_goal(const RS& rs, unsigned long long b, int n_landmarks) {
+    uint32_t r[4];
+    Philox::block(rs.seed, b, rs.episode * 256ull + 255ull, r);
+    return (int)(((uint64_t)r[0] * (uint64_t)n_landmarks) >> 32);
+}
+
 }  // namespace mpe

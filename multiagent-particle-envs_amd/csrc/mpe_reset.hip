@@ -1,4 +1,4 @@
-// On-device Scenario.reset_world: fresh uniform positions, zero velocity and comm state.
+// On-device Scenario.reset_world: fresh uniform positions, zero velocity and comm state, goal landmark.
 //
 // One lane per world.  Entity e of world b in episode n takes its two coordinates from the
 // Philox-4x32-10 block with key = seed and counter = (b, n * 256 + e), so a reset is reproducible
@@ -9,9 +9,9 @@
 namespace mpe {
 
 template <typename T>
-__global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, int comm_rows, bool env_major, const ResetArgs rs,
+__global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, int comm_rows, int n_aux, bool env_major, const ResetArgs rs,
                                                     const uint8_t* __restrict__ mask, T* __restrict__ pos,
-                                                    T* __restrict__ vel, T* __restrict__ comm) {
+                                                    T* __restrict__ vel, T* __restrict__ comm, int32_t* __restrict__ aux) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     if (mask != nullptr && mask[b] == 0) return;
@@ -24,16 +24,17 @@ __global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, i
     }
     for (int r = 0; r < 2 * A; ++r) vel[at(r, 2 * A)] = T(0);
     for (int r = 0; r < comm_rows; ++r) comm[at(r, comm_rows)] = T(0);
+    if (n_aux > 0) aux[at(0, n_aux)] = reset_goal(rs, (unsigned long long)b, E - A);
 }
 
 hipError_t launch_reset(const HostSpec& s, long long B, int dtype, int comm_rows, bool env_major, unsigned long long seed,
-                        unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, hipStream_t st) {
+                        unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, int32_t* aux, hipStream_t st) {
     const ResetArgs rs{1, seed, episode, landmark_limit(s)};
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
     if (dtype == MPE_F64)
-        hipLaunchKernelGGL(reset_kernel<double>, grid, block, 0, st, B, s.E(), s.A, comm_rows, env_major, rs, mask, (double*)pos, (double*)vel, (double*)comm);
+        hipLaunchKernelGGL(reset_kernel<double>, grid, block, 0, st, B, s.E(), s.A, comm_rows, s.n_aux(), env_major, rs, mask, (double*)pos, (double*)vel, (double*)comm, aux);
     else
-        hipLaunchKernelGGL(reset_kernel<float>, grid, block, 0, st, B, s.E(), s.A, comm_rows, env_major, rs, mask, (float*)pos, (float*)vel, (float*)comm);
+        hipLaunchKernelGGL(reset_kernel<float>, grid, block, 0, st, B, s.E(), s.A, comm_rows, s.n_aux(), env_major, rs, mask, (float*)pos, (float*)vel, (float*)comm, aux);
     return hipGetLastError();
 }
 

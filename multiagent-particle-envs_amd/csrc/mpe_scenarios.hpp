@@ -33,6 +33,7 @@ struct SpreadCfg {
     static constexpr int DIM_C = 0, S = 0, N_ACT = A_;
     static constexpr int OBS_DIM = 4 + 2 * L_ + 2 * (A_ - 1);
     static constexpr int OBS_TOTAL = A_ * OBS_DIM;
+    static constexpr int N_AUX = 0;
     static constexpr int NI = A_ + 1;   // collisions per agent, occupied_landmarks
     static constexpr int NF = A_ + 1;   // min_dists, benchmark reward per agent
     // landmarks have collide = False (simple_spread.py:34)
@@ -41,7 +42,7 @@ struct SpreadCfg {
 
     // observation(), simple_spread.py:110-130
     template <typename T, class P>
-    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const P&, T* row) {
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int*, const P&, T* row) {
         int k = 0;
 #pragma unroll
         for (int i = 0; i < A; ++i) {
@@ -63,7 +64,7 @@ struct SpreadCfg {
 
     // reward() :83-108 and benchmark_data() :58-74
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const P& p, T* rew, bool want_info, int* info_i, T* info_f) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int*, const P& p, T* rew, bool want_info, int* info_i, T* info_f) {
         T prox = T(0), min_dists = T(0);
         int occupied = 0;
 #pragma unroll
@@ -107,14 +108,14 @@ struct TagCfg {
     static constexpr int DIM_C = 0, S = 0, N_ACT = 4;
     static constexpr int OBS_ADV = 4 + 2 * L + 2 * (A - 1) + 2, OBS_GOOD = 4 + 2 * L + 2 * (A - 1);
     static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;
-    static constexpr int NI = A, NF = 0;
+    static constexpr int NI = A, NF = 0, N_AUX = 0;
     __host__ __device__ static constexpr bool collides(int) { return true; }   // simple_tag.py:19,30
     __host__ __device__ static constexpr bool speaks(int) { return false; }
     __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
 
     // observation(), simple_tag.py:131-147
     template <typename T, class P>
-    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const P&, T* row) {
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int*, const P&, T* row) {
         int k = 0;
 #pragma unroll
         for (int i = 0; i < A; ++i) {
@@ -137,7 +138,7 @@ struct TagCfg {
 
     // reward() :84-129 and benchmark_data() :57-66
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const P& p, T* rew, bool want_info, int* info_i, T*) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int*, const P& p, T* rew, bool want_info, int* info_i, T*) {
         bool hit[A][N_ADV];   // hit[g][a]: good agent g touches adversary a
         T adv_rew = T(0);
 #pragma unroll
@@ -181,7 +182,7 @@ struct WorldCommCfg {
     static constexpr int OBS_ADV = 4 + 2 * L + 2 * (A - 1) + 2 * (A - N_ADV) + 2 + DIM_C;       // 34
     static constexpr int OBS_GOOD = 4 + 2 * L + 2 * (A - 1) + 2 + 2 * (A - N_ADV - 1);          // 28
     static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;                  // 192
-    static constexpr int NI = A + 2, NF = 0;
+    static constexpr int NI = A + 2, NF = 0, N_AUX = 0;
     // only agents and the obstacle collide (simple_world_comm.py:22,34,41,48)
     __host__ __device__ static constexpr bool collides(int e) { return e <= A; }
     __host__ __device__ static constexpr bool speaks(int i) { return i == 0; }
@@ -204,7 +205,7 @@ struct WorldCommCfg {
 
     // observation(), simple_world_comm.py:224-287
     template <typename T, class P>
-    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const P& p, T* row) {
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const int*, const P& p, T* row) {
         bool inf[A][2];
         forest_bits<T>(pos, p, inf);
         int k = 0;
@@ -243,7 +244,7 @@ struct WorldCommCfg {
 
     // reward() :142-198 and benchmark_data() :115-123; info also carries the integer masks.
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const P& p, T* rew, bool want_info, int* info_i, T*) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int*, const P& p, T* rew, bool want_info, int* info_i, T*) {
         bool hit[A][N_ADV];
 #pragma unroll
         for (int g = N_ADV; g < A; ++g)
@@ -300,6 +301,173 @@ struct WorldCommCfg {
             }
             info_i[A] = fb;
             info_i[A + 1] = vb;
+        }
+    }
+};
+
+// Position of the goal landmark (agent.goal_a): a select chain keeps pos[] in registers.
+template <typename T, int E, int A, int L>
+__device__ __forceinline__ V2<T> goal_of(const V2<T> (&pos)[E], int goal) {
+    V2<T> g = pos[A];
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        g.x = (goal == l) ? pos[A + l].x : g.x;
+        g.y = (goal == l) ? pos[A + l].y : g.y;
+    }
+    return g;
+}
+
+// np.sum(np.square(d)) of a 2-vector
+template <typename T> __device__ __forceinline__ T sq2(T dx, T dy) { return dx * dx + dy * dy; }
+
+// ------------------------------------------------------------------------------------------
+// simple: one agent, one landmark, nothing collides (multiagent/scenarios/simple.py)
+// ------------------------------------------------------------------------------------------
+struct SimpleCfg {
+    static constexpr int A = 1, L = 1, E = 2;
+    static constexpr int DIM_C = 0, S = 0, N_ACT = 1;
+    static constexpr int OBS_TOTAL = 2 + 2 * L;
+    static constexpr int NI = 0, NF = 0, N_AUX = 0;    // no benchmark_data
+    __host__ __device__ static constexpr bool collides(int) { return false; }   // simple.py:12,18
+    __host__ __device__ static constexpr bool speaks(int) { return false; }
+
+    // observation(), simple.py:45-50
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int*, const P&, T* row) {
+        row[0] = vel[0].x; row[1] = vel[0].y;
+        row[2] = pos[1].x - pos[0].x; row[3] = pos[1].y - pos[0].y;
+    }
+
+    // reward(), simple.py:41-43
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int*, const P&, T* rew, bool, int*, T*) {
+        rew[0] = -sq2<T>(pos[0].x - pos[1].x, pos[0].y - pos[1].y);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// simple_adversary: agent 0 is the adversary, 2 good agents, 2 landmarks of which aux[0] is the
+// goal; nothing collides (multiagent/scenarios/simple_adversary.py)
+// ------------------------------------------------------------------------------------------
+struct AdversaryCfg {
+    static constexpr int N_ADV = 1, A = 3, L = 2, E = 5;
+    static constexpr int DIM_C = 0, S = 0, N_ACT = 3;            // world.dim_c = 2 but every agent is silent
+    static constexpr int OBS_ADV = 2 * L + 2 * (A - 1), OBS_GOOD = 2 + OBS_ADV;
+    static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;
+    static constexpr int NI = 1, NF = N_ADV + (A - N_ADV) * (L + 1), N_AUX = 1;
+    __host__ __device__ static constexpr bool collides(int) { return false; }   // simple_adversary.py:19,26
+    __host__ __device__ static constexpr bool speaks(int) { return false; }
+    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
+
+    // observation(), simple_adversary.py:119-138
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&)[A], const T*, const int* aux, const P&, T* row) {
+        const V2<T> g = goal_of<T, E, A, L>(pos, aux[0]);
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            if (!adversary(i)) { row[k++] = g.x - pos[i].x; row[k++] = g.y - pos[i].y; }
+#pragma unroll
+            for (int l = 0; l < L; ++l) { row[k++] = pos[A + l].x - pos[i].x; row[k++] = pos[A + l].y - pos[i].y; }
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i) continue;
+                row[k++] = pos[j].x - pos[i].x; row[k++] = pos[j].y - pos[i].y;
+            }
+        }
+    }
+
+    // reward() :76-116 (shaped branches) and benchmark_data() :56-65
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int* aux, const P&, T* rew, bool want_info, int* info_i, T* info_f) {
+        const V2<T> g = goal_of<T, E, A, L>(pos, aux[0]);
+        T sq[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) sq[i] = sq2<T>(pos[i].x - g.x, pos[i].y - g.y);
+        T adv_rew = T(0);                       // sum([...]) starts from int 0
+#pragma unroll
+        for (int a = 0; a < N_ADV; ++a) adv_rew = adv_rew + t_sqrt<T>(sq[a]);
+        T dmin = t_sqrt<T>(sq[N_ADV]);
+#pragma unroll
+        for (int a = N_ADV + 1; a < A; ++a) dmin = py_min<T>(dmin, t_sqrt<T>(sq[a]));
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            if (adversary(i)) {
+                rew[i] = -sq[i];
+                if (want_info) info_f[k++] = sq[i];
+            } else {
+                rew[i] = -dmin + adv_rew;
+                if (want_info) {
+#pragma unroll
+                    for (int l = 0; l < L; ++l) info_f[k++] = sq2<T>(pos[i].x - pos[A + l].x, pos[i].y - pos[A + l].y);
+                    info_f[k++] = sq[i];
+                }
+            }
+        }
+        if (want_info) info_i[0] = aux[0];
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// simple_push: agent 0 is the adversary, agent 1 the good agent (they collide), 2 landmarks of which
+// aux[0] is the goal (multiagent/scenarios/simple_push.py)
+// ------------------------------------------------------------------------------------------
+struct PushCfg {
+    static constexpr int N_ADV = 1, A = 2, L = 2, E = 4;
+    static constexpr int DIM_C = 0, S = 0, N_ACT = 2;
+    static constexpr int OBS_ADV = 2 + 2 * L + 2 * (A - 1), OBS_GOOD = 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1);
+    static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;
+    static constexpr int NI = 0, NF = 0, N_AUX = 1;     // no benchmark_data
+    __host__ __device__ static constexpr bool collides(int e) { return e < A; }   // simple_push.py:17,28
+    __host__ __device__ static constexpr bool speaks(int) { return false; }
+    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
+
+    // observation(), simple_push.py:75-95.  Colours (reset_world :35-48): landmark l is 0.1 grey with
+    // 0.8 added to channel l + 1; the good agent is 0.25 grey with 0.5 added to channel goal + 1.
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, const P&, T* row) {
+        const int goal = aux[0];
+        const V2<T> g = goal_of<T, E, A, L>(pos, goal);
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            row[k++] = vel[i].x; row[k++] = vel[i].y;
+            if (!adversary(i)) {
+                row[k++] = g.x - pos[i].x; row[k++] = g.y - pos[i].y;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) row[k++] = (ch == goal + 1) ? (T)(0.25 + 0.5) : (T)0.25;
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) { row[k++] = pos[A + l].x - pos[i].x; row[k++] = pos[A + l].y - pos[i].y; }
+            if (!adversary(i)) {
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) row[k++] = (ch == l + 1) ? (T)(0.1 + 0.8) : (T)0.1;
+            }
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i) continue;
+                row[k++] = pos[j].x - pos[i].x; row[k++] = pos[j].y - pos[i].y;
+            }
+        }
+    }
+
+    // reward() :55-73
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int* aux, const P&, T* rew, bool, int*, T*) {
+        const V2<T> g = goal_of<T, E, A, L>(pos, aux[0]);
+        T d[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) d[i] = norm2<T>(pos[i].x - g.x, pos[i].y - g.y);
+        T dmin = d[N_ADV];
+#pragma unroll
+        for (int a = N_ADV + 1; a < A; ++a) dmin = py_min<T>(dmin, d[a]);
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            // adversary: goal - agent, same squares as agent - goal
+            rew[i] = adversary(i) ? dmin - d[i] : -d[i];
         }
     }
 };

@@ -85,9 +85,9 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                                                    T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                    T* __restrict__ obs_g, T* __restrict__ rew_g,
                                                    uint8_t* __restrict__ done_g, int* __restrict__ info_i_g,
-                                                   T* __restrict__ info_f_g, int n_steps) {
+                                                   T* __restrict__ info_f_g, int* __restrict__ aux_g, int n_steps) {
     constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
-    constexpr int NI = Cfg::NI, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C;
+    constexpr int NI = Cfg::NI > 0 ? Cfg::NI : 1, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C, NX = Cfg::N_AUX;
     constexpr bool LIN = ((OT * (int)sizeof(T) / 4) % 16) != 0;
     using ObsTile = Tile<T, OT, LIN, EPW>;
     using RewTile = Tile<T, A, true, EPW>;
@@ -163,6 +163,15 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     V2<T> pos[E];
     V2<T> vel[A];
     T comm[DC > 0 ? DC : 1];
+    int aux[NX > 0 ? NX : 1] = {0};
+    if (NX > 0) {      // goal landmark: drawn with the reset, otherwise the caller's
+        if (MODE == MODE_ROLLOUT && rs.enabled) {
+            aux[0] = reset_goal(rs, (unsigned long long)b, Cfg::L);
+            if (valid) aux_g[b] = aux[0];
+        } else {
+            aux[0] = aux_g[b];
+        }
+    }
     if (MODE == MODE_ROLLOUT && rs.enabled) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
         bool finished = false;
         if (EPW == 64 || lane < EPW) {
             if (want_score)
-                Cfg::template score<T>(pos, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
+                Cfg::template score<T>(pos, aux, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
             if (MODE == MODE_STEP && au.step_count != nullptr) {
                 // ---- episode bookkeeping (mpe_step_auto): returns, step counter, time-limit reset ----
                 T* ep = (T*)au.ep_return + b * A;
@@ -288,6 +297,10 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 #pragma unroll
                         for (int c = 0; c < DC; ++c) comm[c] = T(0);
                     }
+                    if (NX > 0) {
+                        aux[0] = reset_goal(nr, (unsigned long long)b, Cfg::L);
+                        if (valid) aux_g[b] = aux[0];
+                    }
                     if (valid) {
 #pragma unroll
                         for (int e = A; e < E; ++e) {
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
                 }
             }
-            Cfg::template observe<T>(pos, vel, comm, p, ObsTile::row(tile_obs, tile_lane));
+            Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
         }
         __syncthreads();
         const long long row0 = (long long)t * B + env0;
@@ -356,7 +369,7 @@ static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_
     if (env_end <= env_begin) return;
     const dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
     hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
-                       (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
+                       (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.aux, a.n_steps);
 }
 
 // Full tiles run the straight-line FULL instantiation; the ragged tail (and every wave when the
@@ -410,6 +423,13 @@ hipError_t launch_small_t(const HostSpec& s, long long B, int mode, const StepAr
             return launch_cfg<T, TagCfg, true>(s, B, mode, a, st);
         case MPE_SCN_WORLD_COMM:
             return launch_cfg<T, WorldCommCfg, true>(s, B, mode, a, st);
+        // no speed limit in these scenarios; an infinite max_speed makes the clamp a no-op
+        case MPE_SCN_SIMPLE:
+            return launch_cfg<T, SimpleCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_ADVERSARY:
+            return launch_cfg<T, AdversaryCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_PUSH:
+            return launch_cfg<T, PushCfg, true>(s, B, mode, a, st);
     }
     return hipErrorInvalidValue;
 }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "libmpe_hip.so")
 
 MPE_F32, MPE_F64 = 0, 1
-SCN_NONE, SCN_SPREAD, SCN_TAG, SCN_WORLD_COMM = 0, 1, 2, 3
+SCN_NONE, SCN_SPREAD, SCN_TAG, SCN_WORLD_COMM, SCN_SIMPLE, SCN_ADVERSARY, SCN_PUSH = 0, 1, 2, 3, 4, 5, 6
 MAX_AGENTS = 64
 MAX_LANDMARKS = 64
 MAX_WALLS = 16
@@ -37,7 +37,7 @@ class MpeLayout(C.Structure):
     _fields_ = [
         ("n_envs", C.c_int64), ("n_agents", C.c_int32), ("n_landmarks", C.c_int32), ("dim_c", C.c_int32),
         ("n_speakers", C.c_int32), ("n_act", C.c_int32), ("obs_total", C.c_int32),
-        ("n_info_i", C.c_int32), ("n_info_f", C.c_int32), ("state_env_major", C.c_int32), ("reserved", C.c_int32),
+        ("n_info_i", C.c_int32), ("n_info_f", C.c_int32), ("state_env_major", C.c_int32), ("n_aux", C.c_int32),
         ("obs_dim", C.c_int32 * MAX_AGENTS), ("obs_offset", C.c_int32 * MAX_AGENTS),
     ]
 
@@ -54,12 +54,16 @@ EXPORTS = {
     "mpe_destroy": (C.c_int, [C.c_void_p]),
     "mpe_layout": (C.c_int, [C.c_void_p, C.POINTER(MpeLayout)]),
     "mpe_last_error": (C.c_char_p, [C.c_void_p]),
-    "mpe_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]),
-    "mpe_step_auto": (C.c_int, [C.c_void_p] + [C.c_void_p] * 13 + [C.c_int32, C.c_uint64, C.c_void_p]),
-    "mpe_rollout": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
-    "mpe_episode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
-    "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
-    "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 4 + [C.c_void_p]),
+    # (handle, actions, pos, vel, comm, aux, obs, rew, done, info_i, info_f, stream)
+    "mpe_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 10 + [C.c_void_p]),
+    # (..., info_f, step_count, episode_count, ep_return, last_return, max_steps, seed, stream)
+    "mpe_step_auto": (C.c_int, [C.c_void_p] + [C.c_void_p] * 14 + [C.c_int32, C.c_uint64, C.c_void_p]),
+    "mpe_rollout": (C.c_int, [C.c_void_p] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
+    "mpe_episode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
+    # (handle, pos, vel, comm, aux, obs, rew, info_i, info_f, stream)
+    "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]),
+    # (handle, seed, episode, mask, pos, vel, comm, aux, stream)
+    "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
 }
 

@@ -24,6 +24,7 @@ class BatchedEnv:
     Tensors (T = float32 or float64):
       pos   [2E, B]  env-minor entity coordinates (agents first)     vel  [2A, B]
       comm  [S*dim_c, B] comm state of the S speaking agents (or None)
+      aux   [n_aux, B] int32: the goal landmark index of simple_adversary / simple_push (or None)
       (worlds simulated by a whole wave -- ``env_major`` is True -- store these transposed:
       pos [B, 2E], vel [B, 2A], comm [B, S*dim_c]; use get_state / set_state to stay layout-agnostic)
       obs   [B, obs_total]; ``obs_n[i]`` is the view of agent i's columns
@@ -61,9 +62,12 @@ class BatchedEnv:
         self.pos = st(2 * (A + L))
         self.vel = st(2 * A)
         self.comm = st(lo.n_speakers * lo.dim_c) if lo.n_speakers > 0 else None
+        self.aux = z(lo.n_aux, B, dt=torch.int32) if lo.n_aux > 0 else None
         self.obs = z(B, lo.obs_total)
         self.rew = z(B, A)
         self.done = z(B, dt=torch.uint8)
+        if info and lo.n_info_i == 0:
+            raise ValueError("this scenario has no benchmark_data: info is not available")
         self.info_i = z(B, lo.n_info_i, dt=torch.int32) if info else None
         self.info_f = z(B, lo.n_info_f) if (info and lo.n_info_f > 0) else None
         self._episode = 0
@@ -76,7 +80,7 @@ class BatchedEnv:
             self.ep_return = z(B, A)
             self.last_return = z(B, A)
         # raw device pointers of the persistent buffers, resolved once (the tensors are never reallocated)
-        self._p = {k: _ptr(getattr(self, k, None)) for k in ("pos", "vel", "comm", "obs", "rew", "done", "info_i", "info_f",
+        self._p = {k: _ptr(getattr(self, k, None)) for k in ("pos", "vel", "comm", "aux", "obs", "rew", "done", "info_i", "info_f",
                                                              "step_count", "episode_count", "ep_return", "last_return")}
 
     def __del__(self):
@@ -98,7 +102,7 @@ class BatchedEnv:
         """Scenario.observation for every agent of every env on the current state; with ``score``
         also Scenario.reward (into ``rew``) and benchmark_data (into ``info_i`` / ``info_f``)."""
         p = self._p
-        _lib.check(self._h, self._lib.mpe_observe(self._h, p["pos"], p["vel"], p["comm"], p["obs"], p["rew"] if score else None,
+        _lib.check(self._h, self._lib.mpe_observe(self._h, p["pos"], p["vel"], p["comm"], p["aux"], p["obs"], p["rew"] if score else None,
                                                   p["info_i"] if score else None, p["info_f"] if score else None, self._stream()))
         return self.obs
 
@@ -109,7 +113,7 @@ class BatchedEnv:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
         p = self._p
         _lib.check(self._h, self._lib.mpe_reset(self._h, int(seed), self._episode, _ptr(mask), p["pos"], p["vel"], p["comm"],
-                                                self._stream()))
+                                                p["aux"], self._stream()))
         if self.max_episode_steps is not None:
             # the device-side counters restart from this reset: later automatic resets draw episodes
             # self._episode + 1, + 2, ... of the same seed
@@ -140,11 +144,11 @@ class BatchedEnv:
         if self.max_episode_steps is not None:
             # envs that reach max_episode_steps are truncated (done = 1) and reset on device; obs is then the new
             # episode's first observation, last_return the finished episode's return
-            _lib.check(self._h, self._lib.mpe_step_auto(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["obs"], p["rew"], p["done"],
+            _lib.check(self._h, self._lib.mpe_step_auto(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["aux"], p["obs"], p["rew"], p["done"],
                                                         p["info_i"], p["info_f"], p["step_count"], p["episode_count"], p["ep_return"],
                                                         p["last_return"], int(self.max_episode_steps), self.seed, self._stream()))
         else:
-            _lib.check(self._h, self._lib.mpe_step(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["obs"], p["rew"], p["done"],
+            _lib.check(self._h, self._lib.mpe_step(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["aux"], p["obs"], p["rew"], p["done"],
                                                    p["info_i"], p["info_f"], self._stream()))
         return self.obs, self.rew, self.done, (self.info_i, self.info_f)
 
@@ -163,19 +167,20 @@ class BatchedEnv:
                    "info_f": z(T, B, lo.n_info_f) if self.info_f is not None else None}
         p = self._p
         if reset_seed is None:
-            _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], _ptr(out["obs"]),
+            _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["aux"], _ptr(out["obs"]),
                                                       _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]), _ptr(out["info_f"]), T,
                                                       self._stream()))
         else:
             _lib.check(self._h, self._lib.mpe_episode(self._h, int(reset_seed), self._episode, _ptr(a), p["pos"], p["vel"], p["comm"],
-                                                      _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]),
+                                                      p["aux"], _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]),
                                                       _ptr(out["info_f"]), T, self._stream()))
             self._episode += 1
         return out
 
     # ------------------------------------------------------------------
-    def set_state(self, pos, vel, comm=None):
-        """Inject a state given env-major: pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c]."""
+    def set_state(self, pos, vel, comm=None, goal=None):
+        """Inject a state given env-major: pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c], and the goal
+        landmark index [B] of scenarios that have one (kept when None)."""
         B, A, L = self.n_envs, self.n_agents, self.n_landmarks
         lay = (lambda x: x.contiguous()) if self.env_major else (lambda x: x.t().contiguous())
         pos = torch.as_tensor(np.asarray(pos), dtype=self.dtype).reshape(B, 2 * (A + L))
@@ -187,6 +192,10 @@ class BatchedEnv:
                 self.comm.zero_()
             else:
                 self.comm.copy_(lay(torch.as_tensor(np.asarray(comm), dtype=self.dtype).reshape(B, -1)))
+        if goal is not None:
+            if self.aux is None:
+                raise ValueError("this scenario has no goal landmark")
+            self.aux[0].copy_(torch.as_tensor(np.asarray(goal), dtype=torch.int32).reshape(B))
 
     def get_state(self):
         """Returns env-major numpy copies (pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c] or None)."""
@@ -196,6 +205,11 @@ class BatchedEnv:
         vel = lay(self.vel).reshape(B, A, 2).cpu().numpy()
         comm = lay(self.comm).cpu().numpy() if self.comm is not None else None
         return pos, vel, comm
+
+    @property
+    def goal(self):
+        """Goal landmark index per env ([B] int32 view), for scenarios that draw one at reset."""
+        return None if self.aux is None else self.aux[0]
 
     def world_step(self, u, c=None):
         """World.step alone (multiagent/core.py:142-158) for a physics-only handle (scenario id

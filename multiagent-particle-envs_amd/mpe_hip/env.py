@@ -143,8 +143,7 @@ class MultiAgentEnv:
         flat = []
         for i, agent in enumerate(self.agents):
             flat += self._action_ints(action_n[i], agent)
-        pos, vel, comm = world.pack_state()
-        env.set_state(pos, vel, comm)
+        sc.load_state(world, env)
         env.step(torch.tensor([flat], dtype=torch.int32))
         world.t += 1
         world.unpack_state(*env.get_state())

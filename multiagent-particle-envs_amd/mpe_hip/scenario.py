@@ -42,6 +42,7 @@ class HipScenario(BaseScenario):
     scenario_id = _lib.SCN_NONE
     hip_name = ""
     obs_dtype = np.float64
+    has_info = True          # the scenario defines benchmark_data
 
     def __init__(self):
         self._env = None        # (signature, BatchedEnv)
@@ -54,29 +55,44 @@ class HipScenario(BaseScenario):
         sig = world._signature() + (tuple(bool(getattr(a, "adversary", False)) for a in world.agents),)
         if self._env is None or self._env[0] != sig:
             spec = spec_from_world(world, self.scenario_id, self.hip_name)
-            self._env = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=world.device, info=True))
+            self._env = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=world.device, info=self.has_info))
             self._cache = None
         return self._env[1]
 
     @staticmethod
-    def _key(pos, vel, comm):
-        return pos.tobytes() + vel.tobytes() + (comm.tobytes() if comm is not None else b"")
+    def goal_index(world):
+        """Index of the goal landmark the agents share (``agent.goal_a``), or None."""
+        g = getattr(world.agents[0], "goal_a", None)
+        return None if g is None else world.landmarks.index(g)
+
+    @staticmethod
+    def _key(pos, vel, comm, goal):
+        return pos.tobytes() + vel.tobytes() + (comm.tobytes() if comm is not None else b"") + bytes([255 if goal is None else goal])
+
+    @staticmethod
+    def _outputs(env):
+        np_ = lambda t: None if t is None else t[0].cpu().numpy()
+        return env.obs[0].cpu().numpy(), env.rew[0].cpu().numpy(), np_(env.info_i), np_(env.info_f)
+
+    def load_state(self, world, env):
+        """Copy the world's state (and goal landmark) into the one-world batch."""
+        pos, vel, comm = world.pack_state()
+        goal = self.goal_index(world)
+        env.set_state(pos, vel, comm, goal=None if goal is None else [goal])
 
     def store(self, world, env):
         """Cache the callbacks' outputs that ``env`` holds for the world's current state."""
         pos, vel, comm = world.pack_state()
-        self._cache = (self._key(pos, vel, comm), env.obs[0].cpu().numpy(), env.rew[0].cpu().numpy(),
-                       env.info_i[0].cpu().numpy(), env.info_f[0].cpu().numpy() if env.info_f is not None else None)
+        self._cache = (self._key(pos, vel, comm, self.goal_index(world)),) + self._outputs(env)
 
     def evaluate(self, world):
         pos, vel, comm = world.pack_state()
-        key = self._key(pos, vel, comm)
+        key = self._key(pos, vel, comm, self.goal_index(world))
         if self._cache is None or self._cache[0] != key:
             env = self.fused_env(world)
-            env.set_state(pos, vel, comm)
+            self.load_state(world, env)
             env.observe(score=True)
-            self._cache = (key, env.obs[0].cpu().numpy(), env.rew[0].cpu().numpy(), env.info_i[0].cpu().numpy(),
-                           env.info_f[0].cpu().numpy() if env.info_f is not None else None)
+            self._cache = (key,) + self._outputs(env)
         return self._cache
 
     # -- the plugin callbacks --------------------------------------------
@@ -91,4 +107,6 @@ class HipScenario(BaseScenario):
         return float(self.evaluate(world)[2][world.agents.index(agent)])
 
     def benchmark_data(self, agent, world):
+        if not self.has_info:
+            raise AttributeError("scenario %r defines no benchmark_data" % self.hip_name)
         return int(self.evaluate(world)[3][world.agents.index(agent)])

@@ -96,6 +96,37 @@ def world_comm_spec():
                      adversary=adv, leader=leader, name="simple_world_comm")
 
 
+def simple_spec():
+    """simple (multiagent/scenarios/simple.py:6-22): one silent agent and one landmark of the default
+    size 0.05; nothing collides; default acceleration, no speed limit, World.dim_c 0."""
+    return WorldSpec(_lib.SCN_SIMPLE, 1, 1, 0, size=np.full(2, 0.05), mass=np.ones(2),
+                     movable=np.array([True, False]), collide=np.zeros(2, bool),
+                     sensitivity=np.full(1, 5.0), max_speed=np.full(1, np.inf), silent=np.ones(1, bool),
+                     adversary=np.zeros(1, bool), leader=np.zeros(1, bool), name="simple")
+
+
+def adversary_spec():
+    """simple_adversary (multiagent/scenarios/simple_adversary.py:8-33): agent 0 is the adversary,
+    agents 1-2 are good, all of size 0.15, silent and non-colliding; 2 landmarks of size 0.08, one
+    of which is drawn as the goal at every reset."""
+    adv = np.array([True, False, False])
+    return WorldSpec(_lib.SCN_ADVERSARY, 3, 2, 2, size=np.r_[np.full(3, 0.15), np.full(2, 0.08)], mass=np.ones(5),
+                     movable=np.r_[np.ones(3, bool), np.zeros(2, bool)], collide=np.zeros(5, bool),
+                     sensitivity=np.full(3, 5.0), max_speed=np.full(3, np.inf), silent=np.ones(3, bool),
+                     adversary=adv, leader=np.zeros(3, bool), name="simple_adversary")
+
+
+def push_spec():
+    """simple_push (multiagent/scenarios/simple_push.py:6-32): adversary agent 0 and good agent 1 of
+    the default size 0.05 that collide with each other; 2 non-colliding landmarks, one drawn as the
+    goal at every reset."""
+    adv = np.array([True, False])
+    return WorldSpec(_lib.SCN_PUSH, 2, 2, 2, size=np.full(4, 0.05), mass=np.ones(4),
+                     movable=np.r_[np.ones(2, bool), np.zeros(2, bool)], collide=np.r_[np.ones(2, bool), np.zeros(2, bool)],
+                     sensitivity=np.full(2, 5.0), max_speed=np.full(2, np.inf), silent=np.ones(2, bool),
+                     adversary=adv, leader=np.zeros(2, bool), name="simple_push")
+
+
 def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, walls=(), ghost=None, **world):
     """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158); the
     scenario's observation / reward callbacks stay with the caller."""
@@ -114,4 +145,10 @@ def make_spec(name, **kw):
         return tag_spec()
     if name == "simple_world_comm":
         return world_comm_spec()
+    if name == "simple":
+        return simple_spec()
+    if name == "simple_adversary":
+        return adversary_spec()
+    if name == "simple_push":
+        return push_spec()
     raise ValueError("no batched kernel for scenario %r" % (name,))

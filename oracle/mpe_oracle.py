@@ -17,6 +17,8 @@ scalar code so that float64 results are bit-identical, not merely close:
                                    (reference ``World.entities``, multiagent/core.py:127-129)
 * ``vel``  float64 ``[B, A, 2]``   agent velocities (landmarks never move in scope)
 * ``comm`` float64 ``[B, A, dim_c]`` agent communication state ``state.c``
+* ``goal`` int ``[B]``             index of the goal landmark (``agent.goal_a``) in
+                                   simple_adversary / simple_push, drawn by reset_world
 * ``actions`` int ``[B, n_act]``   flattened reference ``action_n`` list: for each agent
                                    its move int 0..4, followed by its comm int if the
                                    agent is not silent (multiagent/environment.py:173-204)
@@ -31,6 +33,9 @@ import numpy as np
 SCN_SPREAD = "simple_spread"
 SCN_TAG = "simple_tag"
 SCN_WORLD_COMM = "simple_world_comm"
+SCN_SIMPLE = "simple"
+SCN_ADVERSARY = "simple_adversary"
+SCN_PUSH = "simple_push"
 
 
 @dataclass
@@ -90,6 +95,12 @@ class Spec:
                     d += self.dim_c
                 out.append(d)
             return out
+        if self.scenario == SCN_SIMPLE:
+            return [2 + 2 * L]
+        if self.scenario == SCN_ADVERSARY:
+            return [(0 if self.adversary[i] else 2) + 2 * L + 2 * (A - 1) for i in range(A)]
+        if self.scenario == SCN_PUSH:
+            return [2 + 2 * L + 2 * (A - 1) if self.adversary[i] else 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1) for i in range(A)]
         raise ValueError(self.scenario)
 
 
@@ -142,7 +153,40 @@ def spec_world_comm() -> Spec:
                 silent=silent, adversary=adv, leader=leader, food=[1, 2], forests=[3, 4])
 
 
+def spec_simple() -> Spec:
+    """simple.make_world, multiagent/scenarios/simple.py:6-22 (World.dim_c stays 0)."""
+    return Spec(SCN_SIMPLE, 1, 1, 0, np.full(2, 0.05), np.array([True, False]), np.zeros(2, bool), np.ones(2),
+                sens=np.full(1, 5.0), max_speed=np.full(1, np.inf), silent=np.ones(1, bool),
+                adversary=np.zeros(1, bool), leader=np.zeros(1, bool))
+
+
+def spec_adversary() -> Spec:
+    """simple_adversary.make_world, multiagent/scenarios/simple_adversary.py:8-33."""
+    A, L = 3, 2
+    adv = np.array([True, False, False])                                   # :22
+    size = np.array([0.15] * A + [0.08] * L)                               # :23, :30
+    return Spec(SCN_ADVERSARY, A, L, 2, size, np.array([True] * A + [False] * L), np.zeros(A + L, bool), np.ones(A + L),
+                sens=np.full(A, 5.0), max_speed=np.full(A, np.inf), silent=np.ones(A, bool),
+                adversary=adv, leader=np.zeros(A, bool))
+
+
+def spec_push() -> Spec:
+    """simple_push.make_world, multiagent/scenarios/simple_push.py:6-32."""
+    A, L = 2, 2
+    adv = np.array([True, False])                                          # :19-22
+    collide = np.array([True] * A + [False] * L)                           # :17, :28
+    return Spec(SCN_PUSH, A, L, 2, np.full(A + L, 0.05), np.array([True] * A + [False] * L), collide, np.ones(A + L),
+                sens=np.full(A, 5.0), max_speed=np.full(A, np.inf), silent=np.ones(A, bool),
+                adversary=adv, leader=np.zeros(A, bool))
+
+
 def make_spec(name: str, **kw) -> Spec:
+    if name == SCN_SIMPLE:
+        return spec_simple()
+    if name == SCN_ADVERSARY:
+        return spec_adversary()
+    if name == SCN_PUSH:
+        return spec_push()
     if name == SCN_SPREAD:
         return spec_spread(**kw)
     if name == SCN_TAG:
@@ -300,11 +344,46 @@ def _bound(x):
     return np.where(x < 0.9, 0.0, np.where(x < 1.0, (x - 0.9) * 10, big))
 
 
-def observe(spec: Spec, pos, vel, comm) -> List[np.ndarray]:
+def _goal_pos(spec: Spec, pos, goal):
+    """Position of each env's goal landmark, [B, 2]."""
+    return pos[np.arange(pos.shape[0]), spec.A + np.asarray(goal)]
+
+
+def observe(spec: Spec, pos, vel, comm, goal=None) -> List[np.ndarray]:
     """Per-agent observations.  Returns a list of A arrays ``[B, D_i]``."""
     A, L = spec.A, spec.L
     B = pos.shape[0]
     out = []
+    if spec.scenario == SCN_SIMPLE:
+        # simple.py:45-50
+        return [np.concatenate([vel[:, 0, :]] + [pos[:, A + l, :] - pos[:, 0, :] for l in range(L)], axis=1)]
+    if spec.scenario == SCN_ADVERSARY:
+        # simple_adversary.py:119-138
+        g = _goal_pos(spec, pos, goal)
+        for i in range(A):
+            parts = [] if spec.adversary[i] else [g - pos[:, i, :]]
+            parts += [pos[:, A + l, :] - pos[:, i, :] for l in range(L)]
+            parts += [pos[:, j, :] - pos[:, i, :] for j in range(A) if j != i]
+            out.append(np.concatenate(parts, axis=1))
+        return out
+    if spec.scenario == SCN_PUSH:
+        # simple_push.py:75-95; colours of reset_world :35-48
+        g = _goal_pos(spec, pos, goal)
+        lm_color = []
+        for l in range(L):
+            c = np.array([0.1, 0.1, 0.1])
+            c[l + 1] += 0.8
+            lm_color.append(np.broadcast_to(c, (B, 3)))
+        for i in range(A):
+            ent = [pos[:, A + l, :] - pos[:, i, :] for l in range(L)]
+            oth = [pos[:, j, :] - pos[:, i, :] for j in range(A) if j != i]
+            if spec.adversary[i]:
+                out.append(np.concatenate([vel[:, i, :]] + ent + oth, axis=1))
+            else:
+                color = np.full((B, 3), 0.25)
+                color[np.arange(B), np.asarray(goal) + 1] += 0.5
+                out.append(np.concatenate([vel[:, i, :], g - pos[:, i, :], color] + ent + lm_color + oth, axis=1))
+        return out
     if spec.scenario == SCN_SPREAD:
         # simple_spread.py:110-130 ; result cast to float32 (:130)
         for i in range(A):
@@ -372,12 +451,39 @@ def visibility_masks(spec: Spec, pos):
     return inf, vis
 
 
-def reward(spec: Spec, pos) -> np.ndarray:
+def _sq(d):
+    """np.sum(np.square(d)) over the last axis of a 2-vector."""
+    sq = np.square(d)
+    return sq[..., 0] + sq[..., 1]
+
+
+def reward(spec: Spec, pos, goal=None) -> np.ndarray:
     """Per-agent rewards ``[B, A]`` float64 (reference mixes Python ints and
     numpy floats; the values are equal)."""
     A, L = spec.A, spec.L
     B = pos.shape[0]
     rew = np.zeros((B, A))
+    if spec.scenario == SCN_SIMPLE:
+        rew[:, 0] = -_sq(pos[:, 0, :] - pos[:, A, :])            # simple.py:41-43
+        return rew
+    if spec.scenario in (SCN_ADVERSARY, SCN_PUSH):
+        g = _goal_pos(spec, pos, goal)
+        good_i = [i for i in range(A) if not spec.adversary[i]]
+        adv_i = [i for i in range(A) if spec.adversary[i]]
+        d = [np.sqrt(_sq(pos[:, i, :] - g)) for i in range(A)]
+        dmin = np.stack([d[i] for i in good_i], axis=0).min(axis=0)
+        if spec.scenario == SCN_ADVERSARY:
+            # simple_adversary.py:76-116, shaped branches
+            adv_rew = np.zeros(B)
+            for a in adv_i:
+                adv_rew = adv_rew + d[a]
+            for i in range(A):
+                rew[:, i] = -_sq(pos[:, i, :] - g) if spec.adversary[i] else -dmin + adv_rew
+        else:
+            # simple_push.py:55-73
+            for i in range(A):
+                rew[:, i] = dmin - np.sqrt(_sq(g - pos[:, i, :])) if spec.adversary[i] else -d[i]
+        return rew
     if spec.scenario == SCN_SPREAD:
         # simple_spread.py:83-108
         for i in range(A):
@@ -437,8 +543,12 @@ def reward(spec: Spec, pos) -> np.ndarray:
     raise ValueError(spec.scenario)
 
 
-def info(spec: Spec, pos):
+def info(spec: Spec, pos, goal=None):
     """benchmark_data.  Returns dict of arrays.
+
+    simple_adversary (simple_adversary.py:56-65): ``sq`` -- per agent the list of
+    squared distances it reports (adversary: to the goal; good: to every landmark,
+    then to the goal), concatenated in agent order [B, 1 + 2 * (L + 1)].
 
     simple_spread (simple_spread.py:58-74): ``rew`` [B, A] float, ``collisions``
     [B, A] int, ``min_dists`` [B] float, ``occupied`` [B] int.
@@ -447,6 +557,14 @@ def info(spec: Spec, pos):
     """
     A, L = spec.A, spec.L
     B = pos.shape[0]
+    if spec.scenario == SCN_ADVERSARY:
+        g = _goal_pos(spec, pos, goal)
+        cols = []
+        for i in range(A):
+            if not spec.adversary[i]:
+                cols += [_sq(pos[:, i, :] - pos[:, A + l, :]) for l in range(L)]
+            cols.append(_sq(pos[:, i, :] - g))
+        return {"sq": np.stack(cols, axis=1)}
     if spec.scenario == SCN_SPREAD:
         min_dists = np.zeros(B)
         r0 = np.zeros(B)
@@ -476,7 +594,7 @@ def info(spec: Spec, pos):
     return {"collisions": coll}
 
 
-def env_step(spec: Spec, pos, vel, actions):
+def env_step(spec: Spec, pos, vel, actions, goal=None):
     """MultiAgentEnv.step, multiagent/environment.py:83-115, for B envs.
 
     Returns (pos, vel, comm, obs_list, rew [B, A], done [B] bool).
@@ -485,8 +603,8 @@ def env_step(spec: Spec, pos, vel, actions):
     """
     u, c = decode_actions(spec, actions)
     pos, vel, comm = world_step(spec, pos, vel, u, c)
-    obs = observe(spec, pos, vel, comm)
-    rew = reward(spec, pos)
+    obs = observe(spec, pos, vel, comm, goal)
+    rew = reward(spec, pos, goal)
     return pos, vel, comm, obs, rew, np.zeros(pos.shape[0], bool)
 
 
@@ -501,7 +619,7 @@ def reset(spec: Spec, rng: np.random.RandomState, B: int = 1):
     """
     A, L = spec.A, spec.L
     pos = np.zeros((B, spec.E, 2))
-    lim = 1.0 if spec.scenario == SCN_SPREAD else 0.9
+    lim = 0.9 if spec.scenario in (SCN_TAG, SCN_WORLD_COMM) else 1.0
     for b in range(B):
         for i in range(A):
             pos[b, i] = rng.uniform(-1, +1, 2)
@@ -511,3 +629,15 @@ def reset(spec: Spec, rng: np.random.RandomState, B: int = 1):
             for l in spec.food + spec.forests:
                 pos[b, A + l] = rng.uniform(-0.9, +0.9, 2)
     return pos, np.zeros((B, A, 2)), np.zeros((B, A, spec.dim_c))
+
+
+def reset_with_goal(spec: Spec, rng: np.random.RandomState, B: int = 1):
+    """reset_world of simple_adversary (:35-54) / simple_push (:34-53): the goal landmark is drawn
+    first (np.random.choice over the landmark list), then the positions as in ``reset``.
+    Returns (pos, vel, comm, goal [B])."""
+    goal = np.zeros(B, np.int64)
+    pos = np.zeros((B, spec.E, 2))
+    for b in range(B):
+        goal[b] = rng.choice(spec.L)
+        pos[b] = reset(spec, rng, 1)[0][0]
+    return pos, np.zeros((B, spec.A, 2)), np.zeros((B, spec.A, spec.dim_c)), goal

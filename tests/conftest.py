@@ -30,6 +30,10 @@ GOLDEN_CASES = {
 }
 
 
+# simple, simple_adversary, simple_push: fixtures also hold the goal landmark index per env
+CLASSIC_CASES = ["simple", "simple_adversary", "simple_push"]
+
+
 @pytest.fixture(scope="session")
 def golden():
     return {k: load_golden(k) for k in GOLDEN_CASES}

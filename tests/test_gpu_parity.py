@@ -506,3 +506,18 @@ def test_world_step_with_walls_matches_reference(dtype):
             pos_prev = pos_prev.copy()
             pos_prev[:, :A] = g["pos"][t]
             vel_prev = g["vel"][t]
+
+
+def test_misaligned_buffer_is_refused():
+    """Rows are stored as 16-byte vectors: the ABI refuses a buffer that is not 16-byte aligned."""
+    import mpe_hip
+    from mpe_hip import _lib
+    env = mpe_hip.BatchedEnv("simple_spread", 64, dtype=torch.float32)
+    env.reset(seed=1)
+    lib = _lib.load()
+    actions = torch.zeros(64, 3, dtype=torch.int32, device="cuda")
+    shifted = torch.zeros(64 * env.layout.obs_total + 1, dtype=torch.float32, device="cuda")[1:]
+    rc = lib.mpe_step(env._h, actions.data_ptr(), env.pos.data_ptr(), env.vel.data_ptr(), None, None, shifted.data_ptr(),
+                      env.rew.data_ptr(), env.done.data_ptr(), None, None, None)
+    assert rc == -1
+    assert b"16-byte aligned" in lib.mpe_last_error(env._h)

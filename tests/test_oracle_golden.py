@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
-from conftest import GOLDEN_CASES, load_golden
+from conftest import CLASSIC_CASES, GOLDEN_CASES, load_golden
 
 
 @pytest.mark.parametrize("case", list(GOLDEN_CASES))
@@ -107,3 +107,30 @@ def test_oracle_reproduces_reference_wall_contact():
         u, c = orc.decode_actions(spec, g["actions"][t])
         pos, vel, _ = orc.world_step(spec, pos, vel, u, c)
         assert np.array_equal(pos[:, :4], g["pos"][t]) and np.array_equal(vel, g["vel"][t]), t
+
+
+@pytest.mark.parametrize("case", CLASSIC_CASES)
+def test_oracle_reproduces_classic_scenarios(case):
+    """simple / simple_adversary / simple_push through the reference's MultiAgentEnv.step, goal
+    landmark from the fixture: state, observations, rewards and benchmark_data bit for bit."""
+    g = load_golden(case)
+    spec = orc.make_spec(case)
+    assert spec.obs_dims == list(g["obs_dims"])
+    goal = g["goal"] if case != "simple" else None
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    for t in range(g["actions"].shape[0]):
+        pos, vel, comm, obs, rew, done = orc.env_step(spec, pos, vel, g["actions"][t], goal)
+        assert np.array_equal(pos[:, :spec.A], g["pos"][t]), (case, t)
+        assert np.array_equal(vel, g["vel"][t]), (case, t)
+        assert np.array_equal(rew, g["rew"][t]), (case, t)
+        assert np.array_equal(np.concatenate(obs, axis=1), g["obs"][t]), (case, t)
+        assert not done.any() and not g["done"][t].any()
+        if "info_sq" in g:
+            assert np.array_equal(orc.info(spec, pos, goal)["sq"], g["info_sq"][t])
+
+
+def test_reset_with_goal_distribution():
+    spec = orc.make_spec("simple_push")
+    pos, vel, comm, goal = orc.reset_with_goal(spec, np.random.RandomState(3), 400)
+    assert set(goal) == {0, 1} and 0.35 < goal.mean() < 0.65
+    assert np.abs(pos).max() <= 1.0 and not vel.any()

@@ -17,6 +17,8 @@ Reference entry points used:
     with ``benchmark_data`` as the info callback (make_env.py:40-41).
     simple_tag's one-argument ``reset_world`` (simple_tag.py:39) is wrapped
     because ``MultiAgentEnv.reset`` passes two (environment.py:119).
+  * simple, simple_adversary, simple_push: ``MultiAgentEnv.step`` likewise; the goal landmark is
+    the reference's own random draw, repeated until it gives the index the fixture asks for.
   * simple_world_comm: the leader's Tuple action cannot pass ``_set_action``
     (environment.py:159-171 only splits MultiDiscrete), so the leader's
     ``action.u`` / ``action.c`` are written with the semantics of
@@ -111,7 +113,7 @@ def load_reference():
     _load("multiagent.multi_discrete", os.path.join(REF, "multiagent", "multi_discrete.py"))
     ref.environment = _load("multiagent.environment", os.path.join(REF, "multiagent", "environment.py"))
     ref.scenarios = {}
-    for n in ("simple_spread", "simple_tag", "simple_world_comm"):
+    for n in ("simple_spread", "simple_tag", "simple_world_comm", "simple", "simple_adversary", "simple_push"):
         ref.scenarios[n] = _load("ref_scn_" + n, os.path.join(REF, "multiagent", "scenarios", n + ".py"))
     return ref
 
@@ -439,6 +441,58 @@ def run_walls(ref):
     return rec
 
 
+def run_classic(ref, name, seed, B=32):
+    """simple / simple_adversary / simple_push through MultiAgentEnv.step.  The goal landmark is the
+    reference's own np.random.choice draw (reset is repeated until it yields the wanted index, so the
+    goal-dependent colours are the ones reset_world assigns); positions are then injected."""
+    sc = ref.scenarios[name].Scenario()
+    world = sc.make_world()
+    info_cb = sc.benchmark_data if hasattr(sc, "benchmark_data") else None
+    env = ref.environment.MultiAgentEnv(world, lambda w, rng: sc.reset_world(w), sc.reward, sc.observation, info_cb)
+    A, L = len(world.agents), len(world.landmarks)
+    rng = np.random.RandomState(seed)
+    pos0 = rng.uniform(-1, 1, (B, A + L, 2))
+    vel0 = np.zeros((B, A, 2))
+    vel0[B // 2:] = rng.uniform(-1, 1, (B - B // 2, A, 2))
+    goal = rng.randint(0, L, B)
+    if name == "simple_push":       # agents start in contact (dist_min = 0.1) in a quarter of the envs
+        for k, b in enumerate(range(0, B, 4)):
+            d = [0.02, 0.05, 0.09, 0.0999, 0.1001, 0.11, 0.15, 0.08][k % 8]
+            ang = rng.uniform(0, 2 * np.pi)
+            pos0[b, 1] = pos0[b, 0] + d * np.array([np.cos(ang), np.sin(ang)])
+    if name == "simple_adversary":  # a good agent sitting on / next to the goal in a few envs
+        for b in range(0, B, 8):
+            pos0[b, 1] = pos0[b, A + goal[b]] + rng.uniform(-0.01, 0.01, 2)
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+    dims = [sp.shape[0] for sp in env.observation_space]
+    rec = {"pos": np.zeros((T_STEPS, B, A, 2)), "vel": np.zeros((T_STEPS, B, A, 2)),
+           "obs": np.zeros((T_STEPS, B, sum(dims))), "obs_dims": np.array(dims, np.int64),
+           "rew": np.zeros((T_STEPS, B, A)), "done": np.zeros((T_STEPS, B), np.uint8), "goal": goal.astype(np.int32)}
+    if info_cb is not None:
+        rec["info_sq"] = np.zeros((T_STEPS, B, 1 + (A - 1) * (L + 1)))
+    env.seed(0)
+    np.random.seed(seed)
+    for b in range(B):
+        for _ in range(1000):
+            env.reset()
+            if not hasattr(world.agents[0], "goal_a") or world.agents[0].goal_a is world.landmarks[goal[b]]:
+                break
+        else:
+            raise RuntimeError("goal draw never matched")
+        inject(world, pos0[b], vel0[b])
+        for t in range(T_STEPS):
+            obs_n, rew_n, done, info_n = env.step([int(a) for a in actions[t, b]])
+            for i, ag in enumerate(world.agents):
+                rec["pos"][t, b, i] = ag.state.p_pos
+                rec["vel"][t, b, i] = ag.state.p_vel
+            rec["obs"][t, b] = np.concatenate([np.asarray(o, np.float64) for o in obs_n])
+            rec["rew"][t, b] = [float(r) for r in rew_n]
+            rec["done"][t, b] = bool(done)
+            if info_cb is not None:
+                rec["info_sq"][t, b] = np.concatenate([np.atleast_1d(np.asarray(x, np.float64)) for x in info_n["n"]])
+    return pos0, vel0, actions, rec
+
+
 def known_answers(ref):
     """Anchors that do not use state injection."""
     out = {}
@@ -510,6 +564,10 @@ def main():
     rec["obs_steps"] = np.array(obs_steps)
     cases["spread64"] = ("simple_spread", dict(A=64, L=64), pos0, vel0, actions, rec)
 
+    for k, (name, seed) in enumerate((("simple", 20240611), ("simple_adversary", 20240612), ("simple_push", 20240613))):
+        pos0, vel0, actions, rec = run_classic(ref, name, seed)
+        cases[name] = (name, {}, pos0, vel0, actions, rec)
+
     for key, (scn, kw, pos0, vel0, actions, rec) in cases.items():
         path = os.path.join(OUT, key + ".npz")
         np.savez_compressed(path, scenario=np.array(scn), pos0=pos0, vel0=vel0,
@@ -530,7 +588,7 @@ def main():
             pos, vel = pos0.copy(), vel0.copy()
             worst = {}
             for t in range(actions.shape[0]):
-                pos, vel, comm, obs, rew, done = orc.env_step(spec, pos, vel, actions[t])
+                pos, vel, comm, obs, rew, done = orc.env_step(spec, pos, vel, actions[t], rec.get("goal"))
                 dev = {
                     "pos": np.abs(pos[:, :spec.A] - rec["pos"][t]).max(),
                     "vel": np.abs(vel - rec["vel"][t]).max(),
@@ -538,6 +596,8 @@ def main():
                 }
                 if "obs_steps" not in rec:
                     dev["obs"] = np.abs(np.concatenate(obs, axis=1) - rec["obs"][t]).max()
+                if "info_sq" in rec:
+                    dev["info_sq"] = np.abs(orc.info(spec, pos, rec["goal"])["sq"] - rec["info_sq"][t]).max()
                 for k, v in dev.items():
                     worst[k] = max(worst.get(k, 0.0), float(v))
             print(key, "oracle-vs-reference max |delta|:", worst)
