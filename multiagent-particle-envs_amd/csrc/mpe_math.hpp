@@ -112,6 +112,25 @@ template <typename T> __device__ __forceinline__ bool touching(V2<T> p1, V2<T> p
     return norm2<T>(p1.x - p2.x, p1.y - p2.y) < dist_min;
 }
 
+// The radicand of norm2, rounded the same way.  sqrt is monotonic, so a minimum over distances can
+// be taken over these and rooted once: min_a sqrt(s_a) == sqrt(min_a s_a) bit for bit.
+template <typename T> __device__ __forceinline__ T sqdist(T dx, T dy) { return dx * dx + dy * dy; }
+template <> __device__ __forceinline__ float sqdist<float>(float dx, float dy) { return __builtin_fmaf(dx, dx, dy * dy); }
+template <typename T> __device__ __forceinline__ T root(T s) { return t_sqrt<T>(s); }
+template <> __device__ __forceinline__ float root<float>(float s) { return __builtin_amdgcn_sqrtf(s); }
+
+// touching() for loops over many pairs: the squared distance decides unless it lies within a few
+// ulps of dist_min^2, where the reference's own comparison sqrt(s) < dist_min is evaluated.  Same
+// truth value as touching() for every input (a NaN distance is "not touching").
+template <typename T> __device__ __forceinline__ bool touching_many(V2<T> p1, V2<T> p2, T dist_min) {
+    const T s = sqdist<T>(p1.x - p2.x, p1.y - p2.y);
+    const T d2 = dist_min * dist_min;
+    const T slack = T(32) * (sizeof(T) == 4 ? T(1.1920929e-7) : T(2.220446049250313e-16));
+    if (s < d2 * (T(1) - slack)) return true;
+    if (!(s < d2 * (T(1) + slack))) return false;
+    return root<T>(s) < dist_min;
+}
+
 // bound(x) of the boundary penalty, simple_tag.py:103-108 / simple_world_comm.py:167-172.
 template <typename T> __device__ __forceinline__ T arena_bound(T x) {
     if (x < T(0.9)) return T(0);

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     __shared__ int coll_idx[MAX_E];     // indices of the colliding entities, ascending
     __shared__ T mind_s[MPE_MAX_LANDMARKS];
     __shared__ int n_coll_s;
+    // the colliding entities packed for the contact loops: (x, y, size) of coll_idx[k]
+    __shared__ __attribute__((aligned(16))) T CP[MAX_E][4];
 
     const int lane = threadIdx.x;      // thread index within the world's workgroup
     const int A = p.A, L = p.L, E = A + L;
@@ -82,6 +84,18 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     const int n_coll = n_coll_s;
     const bool is_agent = lane < A;
     const int me = is_agent ? lane : 0;
+    int my_rank = -1;                   // position of this agent in the list of colliding entities
+    for (int k = 0; k < n_coll; ++k)
+        if (is_agent && coll_idx[k] == me) my_rank = k;
+    for (int k = lane; k < n_coll; k += NT) {
+        const int j = coll_idx[k];
+        CP[k][0] = P[j].x; CP[k][1] = P[j].y; CP[k][2] = size_s[j];
+    }
+    __syncthreads();
+    // A partner further away than this contributes nothing: in float32 the softplus of
+    // -(dist - dist_min) / k is exactly 0 beyond 16.7 k (1 + exp2(..) rounds to 1), in float64 it is
+    // below exp(-60) = 9e-27 beyond 60 k, i.e. a force under 1e-27.
+    const T cut = (sizeof(T) == 4 ? T(18) : T(60)) * p.contact_margin;
     const bool i_collide = tb->collide[me] != 0;
     const T my_size = size_s[me];
     const T my_mass = (T)tb->mass[me];
@@ -105,14 +119,40 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                     f.y = is_agent ? u_g[b * (2 * A) + 2 * lane + 1] : T(0);
                 }
                 // ---- contact forces: partners in ascending entity order (core.py:170-181) ----
+                // Pass 1 marks the partners within reach (squared distances only, one LDS read each);
+                // pass 2 evaluates the softplus force for those, every lane walking its own set bits
+                // in ascending order.  A NaN distance counts as within reach, so NaNs spread exactly
+                // as in the reference.
                 if (i_collide) {
+                    const T reach0 = my_size + cut;
+                    unsigned near[MAX_E / 32];
+#pragma unroll
+                    for (int w = 0; w < MAX_E / 32; ++w) {
+                        unsigned word = 0;
+                        const int k0 = 32 * w, k1 = (n_coll - k0 < 32) ? n_coll - k0 : 32;
 #pragma unroll 8
-                    for (int k = 0; k < n_coll; ++k) {
-                        const int j = coll_idx[k];
-                        if (j == me) continue;
-                        const V2<T> g = contact_force<T>(pi, P[j], my_size + size_s[j], p.contact_force, p.contact_margin);
-                        f.x = g.x + f.x;
-                        f.y = g.y + f.y;
+                        for (int kk = 0; kk < k1; ++kk) {
+                            const T* c = CP[k0 + kk];
+                            const T reach = reach0 + c[2];
+                            const T s2 = sqdist<T>(pi.x - c[0], pi.y - c[1]);
+                            word |= !(s2 >= reach * reach) ? (1u << kk) : 0u;
+                        }
+                        if ((my_rank >> 5) == w) word &= ~(1u << (my_rank & 31));     // not with itself
+                        near[w] = word;
+                    }
+#pragma unroll
+                    for (int w = 0; w < MAX_E / 32; ++w) {
+                        unsigned word = near[w];
+                        while (word != 0) {
+                            const int kk = __ffs(word) - 1;
+                            word &= word - 1;
+                            const T* c = CP[32 * w + kk];
+                            V2<T> pj;
+                            pj.x = c[0]; pj.y = c[1];
+                            const V2<T> g = contact_force<T>(pi, pj, my_size + c[2], p.contact_force, p.contact_margin);
+                            f.x = g.x + f.x;
+                            f.y = g.y + f.y;
+                        }
                     }
                 }
                 // ---- wall contact, after the entity contacts (core.py:182-188) ----
@@ -132,7 +172,10 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                 integrate<T, CLAMP>(pi, vi, f, my_mass, my_max_speed, p.one_minus_damping, p.dt);   // core.py:193-204
             }
             __syncthreads();            // every lane has read the old positions
-            if (is_agent) { P[lane] = pi; Vel[lane] = vi; }
+            if (is_agent) {
+                P[lane] = pi; Vel[lane] = vi;
+                if (my_rank >= 0) { CP[my_rank][0] = pi.x; CP[my_rank][1] = pi.y; }
+            }
             __syncthreads();
             if (EPI == EPI_NONE) {
                 // update_agent_state (core.py:206-212): speakers copy their comm action
@@ -146,9 +189,10 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                 // ---- reward() :83-108 and benchmark_data() :58-74 ----
                 if (lane < L) {
                     const V2<T> pl = P[A + lane];
-                    T m = norm2<T>(P[0].x - pl.x, P[0].y - pl.y);
-                    for (int a = 1; a < A; ++a) m = py_min<T>(m, norm2<T>(P[a].x - pl.x, P[a].y - pl.y));
-                    mind_s[lane] = m;
+                    // min over agents of the distance: minimum of the squared distances, rooted once
+                    T m = sqdist<T>(P[0].x - pl.x, P[0].y - pl.y);
+                    for (int a = 1; a < A; ++a) m = py_min<T>(m, sqdist<T>(P[a].x - pl.x, P[a].y - pl.y));
+                    mind_s[lane] = root<T>(m);
                 }
                 __syncthreads();
                 if (is_agent) {
@@ -165,7 +209,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                     const V2<T> pi = P[lane];
                     for (int a = 0; a < A; ++a) {
                         if (a == lane) continue;
-                        if (touching<T>(P[a], pi, size_s[a] + my_size)) { c += 1; bench = bench - T(1); }
+                        if (touching_many<T>(P[a], pi, size_s[a] + my_size)) { c += 1; bench = bench - T(1); }
                     }
                     const T r_me = (lane == 0 ? prox : T(0)) + (T)(-c);
                     rew_g[row * A + lane] = r_me;
@@ -213,6 +257,11 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                         }
                     }
                     if (is_agent) { Vel[lane].x = T(0); Vel[lane].y = T(0); }
+                    __syncthreads();
+                    for (int k = lane; k < n_coll; k += NT) {       // keep the packed copy in step
+                        const int j = coll_idx[k];
+                        CP[k][0] = P[j].x; CP[k][1] = P[j].y;
+                    }
                     __syncthreads();
                 }
             }
