@@ -39,8 +39,11 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                                                   T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                   T* __restrict__ obs_g, T* __restrict__ rew_g, uint8_t* __restrict__ done_g,
                                                   int* __restrict__ info_i_g, T* __restrict__ info_f_g, int n_steps) {
-    __shared__ V2<T> P[MAX_E];          // entity positions, agents first
-    __shared__ V2<T> Vel[MPE_MAX_AGENTS];
+    // entity positions (agents first) and agent velocities in one array, so that the observation
+    // loop can fetch either with one computed index
+    __shared__ V2<T> PV[MAX_E + MPE_MAX_AGENTS];
+    V2<T>* const P = PV;
+    V2<T>* const Vel = PV + MAX_E;
     __shared__ T size_s[MAX_E];
     __shared__ int coll_idx[MAX_E];     // indices of the colliding entities, ascending
     __shared__ T mind_s[MPE_MAX_LANDMARKS];
@@ -187,30 +190,38 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
             bool finished = false;
             if (MODE != WMODE_OBSERVE || rew_g != nullptr) {
                 // ---- reward() :83-108 and benchmark_data() :58-74 ----
-                if (lane < L) {
-                    const V2<T> pl = P[A + lane];
+                // the second wave takes the landmark minima while the agents' wave counts collisions
+                const int lm = lane - 64;
+                if (lm >= 0 && lm < L) {
+                    const V2<T> pl = P[A + lm];
                     // min over agents of the distance: minimum of the squared distances, rooted once
                     T m = sqdist<T>(P[0].x - pl.x, P[0].y - pl.y);
+#pragma unroll 8
                     for (int a = 1; a < A; ++a) m = py_min<T>(m, sqdist<T>(P[a].x - pl.x, P[a].y - pl.y));
-                    mind_s[lane] = root<T>(m);
+                    mind_s[lm] = root<T>(m);
+                }
+                int c = 0;              // collisions of this agent, counted while the other wave takes the minima
+                if (is_agent) {
+                    const V2<T> pi = P[lane];
+#pragma unroll 8
+                    for (int a = 0; a < A; ++a) {
+                        if (a == lane) continue;
+                        c += touching_many<T>(P[a], pi, size_s[a] + my_size) ? 1 : 0;
+                    }
                 }
                 __syncthreads();
                 if (is_agent) {
                     T prox = T(0), min_dists = T(0);
                     int occupied = 0;
+#pragma unroll 8
                     for (int l = 0; l < L; ++l) {       // every agent thread repeats the short ordered sum
                         const T m = mind_s[l];
                         prox = prox - m;
                         min_dists = min_dists + m;
                         occupied += (m < T(0.1)) ? 1 : 0;
                     }
-                    int c = 0;
                     T bench = prox;
-                    const V2<T> pi = P[lane];
-                    for (int a = 0; a < A; ++a) {
-                        if (a == lane) continue;
-                        if (touching_many<T>(P[a], pi, size_s[a] + my_size)) { c += 1; bench = bench - T(1); }
-                    }
+                    for (int n = 0; n < c; ++n) bench = bench - T(1);      // rew -= 1 per collision (:106)
                     const T r_me = (lane == 0 ? prox : T(0)) + (T)(-c);
                     rew_g[row * A + lane] = r_me;
                     if (MODE == WMODE_STEP && au.step_count != nullptr) {
@@ -265,30 +276,28 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                     __syncthreads();
                 }
             }
-            // ---- observation(), simple_spread.py:110-130: rows of OD/2 coordinate pairs ----
+            // ---- observation(), simple_spread.py:110-130: rows of RP = OD/2 coordinate pairs ----
+            // Pair r of agent i's row is Vel[i] (r = 0), P[i] (r = 1) or P[src] - P[i]; the loop is branch-
+            // free (one computed index into PV, the subtrahend masked out for r < 2) so that the LDS
+            // reads of several iterations are in flight together, and (i, r) advance incrementally.
             const int RP = OD / 2, total = A * RP;
-            const float inv_rp = 1.0f / (float)RP;    // q <= 64 * 129: (q + 0.5) / RP floors exactly in float
-            T* obs_env = obs_g + row * (long long)(A * OD);
+            typedef T T2 __attribute__((ext_vector_type(2)));
+            // the world's block starts at a multiple of A*OD values and OD is even: pair q is 2*sizeof(T)-aligned
+            T2* dst = reinterpret_cast<T2*>(obs_g + row * (long long)(A * OD)) + lane;
+            int i = (int)(((float)lane + 0.5f) / (float)RP), r = lane - i * RP;      // lane < 128: exact
             #pragma unroll 4
-            for (int q = lane; q < total; q += NT) {
-                const int i = (int)(((float)q + 0.5f) * inv_rp), r = q - i * RP;
-                V2<T> o;
-                if (r == 0) o = Vel[i];
-                else if (r == 1) o = P[i];
-                else {
-                    int src;
-                    if (r < 2 + L) src = A + (r - 2);
-                    else { const int m = r - 2 - L; src = m + (m >= i ? 1 : 0); }
-                    o.x = P[src].x - P[i].x;
-                    o.y = P[src].y - P[i].y;
-                }
-                // one 2-vector store per pair: the world's block starts at a multiple of A*OD values and
-                // OD is even, so pair q is 2*sizeof(T)-aligned
-                typedef T T2 __attribute__((ext_vector_type(2)));
+            for (int q = lane; q < total; q += NT, dst += NT) {
+                const int m = r - 2 - L;
+                const int src = (m < 0) ? A + r - 2 : m + (m >= i ? 1 : 0);
+                const int first = (r == 0) ? MAX_E + i : (r == 1 ? i : src);
+                const V2<T> sa = PV[first], sb = PV[i];
+                const bool rel = r >= 2;
                 T2 w;
-                w.x = spread_round<T>(o.x);
-                w.y = spread_round<T>(o.y);
-                reinterpret_cast<T2*>(obs_env)[q] = w;
+                w.x = spread_round<T>(sa.x - (rel ? sb.x : T(0)));
+                w.y = spread_round<T>(sa.y - (rel ? sb.y : T(0)));
+                *dst = w;
+                r += NT;
+                while (r >= RP) { r -= RP; ++i; }       // once when RP >= 128; worlds with a short row have few pairs
             }
         }
     }
