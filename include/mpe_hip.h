@@ -22,18 +22,25 @@
  *   pos      T[2E][B]        row 2e+d holds coordinate d of entity e for every env (env-minor)
  *   vel      T[2A][B]        same for agent velocities (landmarks never move)
  *   comm     T[S*dim_c][B]   state.c of the S non-silent agents, in agent order (may be NULL if S == 0)
- *   aux      int32[n_aux][B] what reset_world draws besides positions and keeps for the episode:
- *                            row 0 is the index of the goal landmark (agent.goal_a) in
- *                            simple_adversary and simple_push (may be NULL if n_aux == 0)
+ *   aux      int32[n_aux][B] landmark indices reset_world draws besides positions and keeps for the
+ *                            episode (may be NULL if n_aux == 0): row 0 is the goal landmark
+ *                            (agent.goal_a) in simple_adversary and simple_push and the listener's
+ *                            target (agents[0].goal_b) in simple_speaker_listener; rows 0 and 1 are
+ *                            goal_b of agent 0 and of agent 1 in simple_reference, and the goal landmark
+ *                            and the landmark whose colour is the speaker's key in simple_crypto
  *     Small worlds (one lane simulates one world) keep this env-minor layout so that a wave's 64
  *     worlds load as coalesced rows.  Worlds simulated by a whole wave (MpeLayout.state_env_major
  *     == 1: simple_spread other than 3/3, and MPE_SCN_NONE) store the state arrays transposed,
  *     pos T[B][2E], vel T[B][2A], comm T[B][S*dim_c], so that one world is contiguous.
  *   actions  int32[B][n_act] per env, the reference's action_n list flattened: for each agent its
- *                            move int 0..4, followed by its comm int 0..dim_c-1 if it is not silent
+ *                            move int 0..4 if it is movable, followed by its comm int 0..dim_c-1 if
+ *                            it is not silent (environment.py:173-204)
  *   obs      T[B][obs_total] per env, the agents' observation vectors concatenated in agent order;
  *                            agent i owns columns [obs_offset[i], obs_offset[i] + obs_dim[i])
- *   rew      T[B][A]
+ *   rew      T[B][A]         what step returns: in a collaborative world (World.collaborative:
+ *                            simple_speaker_listener, simple_reference) every agent's entry is the
+ *                            sum of the agents' own rewards (environment.py:103-105); mpe_observe
+ *                            writes the own rewards, which is what the reward callback returns
  *   done     uint8[B]        0: no in-scope scenario has a done callback (environment.py:143-146);
  *                            mpe_step_auto sets it to 1 on the step that reaches its time limit
  *   info_i   int32[B][n_info_i]   optional (NULL to skip), see mpe_layout
@@ -64,6 +71,9 @@ extern "C" {
 #define MPE_SCN_SIMPLE 4     /* multiagent/scenarios/simple.py */
 #define MPE_SCN_ADVERSARY 5  /* multiagent/scenarios/simple_adversary.py */
 #define MPE_SCN_PUSH 6       /* multiagent/scenarios/simple_push.py */
+#define MPE_SCN_SPEAKER_LISTENER 7 /* multiagent/scenarios/simple_speaker_listener.py */
+#define MPE_SCN_REFERENCE 8  /* multiagent/scenarios/simple_reference.py */
+#define MPE_SCN_CRYPTO 9     /* multiagent/scenarios/simple_crypto.py */
 
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_LANDMARKS 64
@@ -86,7 +96,7 @@ typedef struct MpeSpec {
     double contact_margin; /* World.contact_margin (1e-3) */
     const double* size;       /* [E] Entity.size */
     const double* mass;       /* [E] Entity.mass */
-    const uint8_t* movable;   /* [E] Entity.movable */
+    const uint8_t* movable;   /* [E] Entity.movable; landmarks must be 0, agents 1 unless the scenario says otherwise */
     const uint8_t* collide;   /* [E] Entity.collide */
     const double* sensitivity; /* [A] Agent.accel, or 5.0 when accel is None (environment.py:192-195) */
     const double* max_speed;  /* [A] Entity.max_speed, or +inf when None (core.py:199) */
@@ -96,7 +106,8 @@ typedef struct MpeSpec {
     /* World.walls (core.py:26-42), simulated by mpe_world_step only (MPE_SCN_NONE); n_walls == 0
      * and NULL pointers for the built-in scenarios, none of which has walls. */
     int32_t n_walls;
-    int32_t reserved;
+    int32_t collaborative; /* World.collaborative (environment.py:38): must match the scenario (1 for
+                              simple_speaker_listener and simple_reference, 0 for the others) */
     const uint8_t* wall_vertical;  /* [W] 0: orient 'H' (lies along x at y = axis_pos), 1: orient 'V' */
     const double* wall_axis_pos;   /* [W] Wall.axis_pos */
     const double* wall_end0;       /* [W] Wall.endpoints[0] */
@@ -111,7 +122,7 @@ typedef struct MpeLayout {
     int64_t n_envs;
     int32_t n_agents, n_landmarks, dim_c;
     int32_t n_speakers;  /* S: agents with silent == 0 */
-    int32_t n_act;       /* A + S */
+    int32_t n_act;       /* movable agents + S */
     int32_t obs_total;   /* sum of obs_dim */
     int32_t n_info_i;    /* simple_spread: A collision counts + occupied_landmarks;
                             simple_tag: A collision counts;
@@ -119,11 +130,17 @@ typedef struct MpeLayout {
                             + visibility bits (agent i sees its k-th other agent, others in
                             ascending order skipping i: bit (A-1)*i+k);
                             simple_adversary: the goal landmark index;
+                            simple_speaker_listener, simple_reference, simple_crypto: the aux rows;
                             simple, simple_push: none (no benchmark_data), info_i must be NULL */
     int32_t n_info_f;    /* simple_spread: min_dists + A benchmark rewards;
                             simple_adversary: benchmark_data (simple_adversary.py:56-65) flattened in
                             agent order: the adversary's squared goal distance, then per good agent
-                            its squared distance to each landmark and to the goal; otherwise 0 */
+                            its squared distance to each landmark and to the goal;
+                            simple_speaker_listener, simple_reference: the A own rewards before sharing
+                            (info_n['r<i>'], environment.py:100);
+                            simple_crypto: benchmark_data (simple_crypto.py:78-80) per agent: its
+                            utterance state.c[dim_c], then the goal landmark's colour [dim_c];
+                            otherwise 0 */
     int32_t state_env_major; /* 0: pos/vel/comm are [rows][B]; 1: [B][rows] (see "Memory layout") */
     int32_t n_aux;       /* rows of aux */
     int32_t obs_dim[MPE_MAX_AGENTS];
@@ -198,9 +215,10 @@ int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm
 /*
  * Scenario.reset_world (simple_spread.py:40-56, simple_tag.py:39-54, simple_world_comm.py:88-113)
  * for every env whose mask byte is non-zero (all envs when mask is NULL): agent positions
- * U(-1,1)^2, landmark positions U(-1,1)^2 (simple_spread, simple, simple_adversary, simple_push) or
- * U(-0.9,0.9)^2, zero velocity and comm; the goal landmark of simple_adversary (:41-45) and
- * simple_push (:40-42) uniform over the landmarks.
+ * U(-1,1)^2, landmark positions U(-0.9,0.9)^2 (simple_tag, simple_world_comm) or U(-1,1)^2 (all
+ * others), zero velocity and comm; the aux landmark indices (goal of simple_adversary.py:41-45,
+ * simple_push.py:40-42, simple_speaker_listener.py:40; both goal_b of simple_reference.py:33-35; goal
+ * and key of simple_crypto.py:61-63) uniform over the landmarks.
  * Draws come from a counter-based generator keyed by (seed, env index, episode); they follow the
  * reference's distributions, not numpy's Mersenne-Twister stream.
  */

@@ -40,12 +40,37 @@ static int hip_fail(MpeHandle* h, hipError_t e, const char* what) {
 // disagrees with it instead of silently simulating something else.
 static const char* check_structure(const HostSpec& s) {
     const int A = s.A, L = s.L;
-    for (int i = 0; i < A; ++i)
-        if (!s.movable[i]) return "agents must be movable";
     for (int l = 0; l < L; ++l)
         if (s.movable[A + l]) return "landmarks must not be movable";
+    const bool shared = s.scenario == MPE_SCN_SPEAKER_LISTENER || s.scenario == MPE_SCN_REFERENCE;
+    if (s.scenario != MPE_SCN_NONE && (s.collaborative != 0) != shared)
+        return shared ? "the scenario shares rewards: collaborative must be 1" : "the scenario does not share rewards: collaborative must be 0";
+    switch (s.scenario) {
+        case MPE_SCN_SPEAKER_LISTENER:
+            if (A != 2 || L != 3 || s.dim_c != 3) return "simple_speaker_listener has 2 agents, 3 landmarks, dim_c 3";
+            if (s.movable[0] || s.silent[0] || !s.movable[1] || !s.silent[1]) return "simple_speaker_listener: agent 0 speaks and cannot move, agent 1 moves and is silent";
+            for (int e = 0; e < A + L; ++e)
+                if (s.collide[e]) return "simple_speaker_listener: nothing collides";
+            return nullptr;
+        case MPE_SCN_CRYPTO:
+            if (A != 3 || L != 2 || s.dim_c != 4) return "simple_crypto has 3 agents, 2 landmarks, dim_c 4";
+            for (int i = 0; i < A; ++i)
+                if (s.movable[i] || s.silent[i] || s.adversary[i] != (i < 1)) return "simple_crypto agents speak and cannot move, agent 0 is the adversary";
+            return nullptr;
+        default:
+            break;
+    }
+    for (int i = 0; i < A; ++i)
+        if (!s.movable[i] && s.scenario != MPE_SCN_NONE) return "agents must be movable";
     switch (s.scenario) {
         case MPE_SCN_NONE:
+            return nullptr;
+        case MPE_SCN_REFERENCE:
+            if (A != 2 || L != 3 || s.dim_c != 10) return "simple_reference has 2 agents, 3 landmarks, dim_c 10";
+            for (int i = 0; i < A; ++i)
+                if (s.silent[i]) return "simple_reference agents speak";
+            for (int e = 0; e < A + L; ++e)
+                if (s.collide[e]) return "simple_reference: nothing collides";
             return nullptr;
         case MPE_SCN_SPREAD:
             for (int i = 0; i < A; ++i)
@@ -97,13 +122,15 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
     lo->n_agents = A;
     lo->n_landmarks = L;
     lo->dim_c = s.dim_c;
-    int speakers = 0, n_good = 0;
+    int speakers = 0, n_good = 0, movers = 0;
     for (int i = 0; i < A; ++i) {
         speakers += s.silent[i] ? 0 : 1;
         n_good += s.adversary[i] ? 0 : 1;
+        movers += s.movable[i] ? 1 : 0;
     }
     lo->n_speakers = speakers;
-    lo->n_act = A + speakers;
+    // MPE_SCN_NONE takes forces for every agent (mpe_world_step), not int actions
+    lo->n_act = (s.scenario == MPE_SCN_NONE ? A : movers) + speakers;
     int off = 0;
     for (int i = 0; i < A; ++i) {
         int d = 0;
@@ -115,6 +142,9 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
             case MPE_SCN_SIMPLE: d = 2 + 2 * L; break;
             case MPE_SCN_ADVERSARY: d = (s.adversary[i] ? 0 : 2) + 2 * L + 2 * (A - 1); break;
             case MPE_SCN_PUSH: d = s.adversary[i] ? 2 + 2 * L + 2 * (A - 1) : 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1); break;
+            case MPE_SCN_SPEAKER_LISTENER: d = (i == 0) ? 3 : 2 + 2 * L + s.dim_c; break;
+            case MPE_SCN_REFERENCE: d = 2 + 2 * L + 3 + s.dim_c; break;
+            case MPE_SCN_CRYPTO: d = (i == 0) ? s.dim_c : 2 * s.dim_c; break;
             default: d = 0;
         }
         lo->obs_dim[i] = d;
@@ -127,6 +157,9 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
         case MPE_SCN_TAG: lo->n_info_i = A; break;
         case MPE_SCN_WORLD_COMM: lo->n_info_i = A + 2; break;
         case MPE_SCN_ADVERSARY: lo->n_info_i = 1; lo->n_info_f = 1 + (A - 1) * (L + 1); break;
+        case MPE_SCN_SPEAKER_LISTENER: lo->n_info_i = 1; lo->n_info_f = A; break;
+        case MPE_SCN_REFERENCE: lo->n_info_i = 2; lo->n_info_f = A; break;
+        case MPE_SCN_CRYPTO: lo->n_info_i = 2; lo->n_info_f = A * 2 * s.dim_c; break;
         default: break;
     }
     lo->n_aux = s.n_aux();
@@ -152,7 +185,7 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     if (!h) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: out of host memory");
     memset(h, 0, sizeof(*h));
     HostSpec& s = h->spec;
-    s.scenario = spec->scenario; s.A = A; s.L = L; s.dim_c = spec->dim_c;
+    s.scenario = spec->scenario; s.A = A; s.L = L; s.dim_c = spec->dim_c; s.collaborative = spec->collaborative ? 1 : 0;
     s.dt = spec->dt; s.damping = spec->damping; s.contact_force = spec->contact_force; s.contact_margin = spec->contact_margin;
     for (int e = 0; e < A + L; ++e) {
         s.size[e] = spec->size[e]; s.mass[e] = spec->mass[e];

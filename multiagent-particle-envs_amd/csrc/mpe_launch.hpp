@@ -12,7 +12,7 @@ constexpr int MAX_E = MPE_MAX_AGENTS + MPE_MAX_LANDMARKS;
 
 // Validated copy of MpeSpec (host memory).
 struct HostSpec {
-    int scenario, A, L, dim_c;
+    int scenario, A, L, dim_c, collaborative;
     double dt, damping, contact_force, contact_margin;
     double size[MAX_E], mass[MAX_E];
     uint8_t movable[MAX_E], collide[MAX_E];
@@ -22,8 +22,14 @@ struct HostSpec {
     uint8_t wall_vertical[MPE_MAX_WALLS], wall_hard[MPE_MAX_WALLS];
     double wall_axis_pos[MPE_MAX_WALLS], wall_end0[MPE_MAX_WALLS], wall_end1[MPE_MAX_WALLS], wall_width[MPE_MAX_WALLS];
     int E() const { return A + L; }
-    // rows of per-episode scenario state: the goal landmark index of simple_adversary / simple_push
-    int n_aux() const { return (scenario == MPE_SCN_ADVERSARY || scenario == MPE_SCN_PUSH) ? 1 : 0; }
+    // rows of per-episode scenario state: the landmark indices reset_world draws
+    int n_aux() const {
+        switch (scenario) {
+            case MPE_SCN_ADVERSARY: case MPE_SCN_PUSH: case MPE_SCN_SPEAKER_LISTENER: return 1;
+            case MPE_SCN_REFERENCE: case MPE_SCN_CRYPTO: return 2;
+            default: return 0;
+        }
+    }
     bool any_speed_limit() const {
         for (int i = 0; i < A; ++i) if (isfinite(max_speed[i])) return true;
         return false;
@@ -67,7 +73,7 @@ struct StepArgs {
     int n_steps;
     ResetArgs reset;
     AutoArgs au;
-    int32_t* aux;             // [n_aux][B] per-episode scenario state (goal landmark index), or NULL
+    int32_t* aux;             // [n_aux][B] per-episode scenario state (landmark indices), or NULL
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112

@@ -233,14 +233,16 @@ __host__ __device__ inline V2<double> reset_draw(const RS& rs, unsigned long lon
     return d;
 }
 
-// Index of the goal landmark (np.random.choice(world.landmarks), simple_adversary.py:42,
-// simple_push.py:41) of world `b` in episode rs.episode: uniform over n_landmarks, from the Philox
-// block with counter (b, episode * 256 + 255), which no entity uses.
+// k-th landmark index that reset_world draws with np.random.choice(world.landmarks) (the goal of
+// simple_adversary.py:42 / simple_push.py:41 / simple_speaker_listener.py:40; goal_b of both agents,
+// simple_reference.py:33-35; goal and key, simple_crypto.py:61-63) of world `b` in episode
+// rs.episode: uniform over n_landmarks, from word k (< 4) of the Philox block with counter
+// (b, episode * 256 + 255), which no entity uses.
 template <class RS>
-__host__ __device__ inline int reset_goal(const RS& rs, unsigned long long b, int n_landmarks) {
+__host__ __device__ inline int reset_aux(const RS& rs, unsigned long long b, int k, int n_landmarks) {
     uint32_t r[4];
     Philox::block(rs.seed, b, rs.episode * 256ull + 255ull, r);
-    return (int)(((uint64_t)r[0] * (uint64_t)n_landmarks) >> 32);
+    return (int)(((uint64_t)r[k] * (uint64_t)n_landmarks) >> 32);
 }
 
 }  // namespace mpe

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, i
     }
     for (int r = 0; r < 2 * A; ++r) vel[at(r, 2 * A)] = T(0);
     for (int r = 0; r < comm_rows; ++r) comm[at(r, comm_rows)] = T(0);
-    if (n_aux > 0) aux[at(0, n_aux)] = reset_goal(rs, (unsigned long long)b, E - A);
+    for (int k = 0; k < n_aux; ++k) aux[at(k, n_aux)] = reset_aux(rs, (unsigned long long)b, k, E - A);
 }
 
 hipError_t launch_reset(const HostSpec& s, long long B, int dtype, int comm_rows, bool env_major, unsigned long long seed,

@@ -20,6 +20,15 @@ struct SmallParams {
     long long n_envs;
 };
 
+// Defaults of a scenario description; a scenario overrides what differs.
+struct CfgBase {
+    static constexpr int BITS = 3;          // bits kept of every action int (moves 0..4, comm words 0..dim_c-1)
+    static constexpr bool SHARED = false;   // World.collaborative: step returns the summed reward to every agent
+    static constexpr int N_AUX = 0;         // landmark indices reset_world draws and keeps for the episode
+    __host__ __device__ static constexpr bool movable(int) { return true; }    // Agent.movable
+    __host__ __device__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
+};
+
 // simple_spread casts its observation to float32 (simple_spread.py:130); the float64 kernel keeps
 // that rounding so it can be compared bit for bit.
 template <typename T> __device__ __forceinline__ T round_f32(T v) { return (T)(float)v; }
@@ -28,7 +37,7 @@ template <typename T> __device__ __forceinline__ T round_f32(T v) { return (T)(f
 // simple_spread with A agents and L landmarks (multiagent/scenarios/simple_spread.py)
 // ------------------------------------------------------------------------------------------
 template <int A_, int L_>
-struct SpreadCfg {
+struct SpreadCfg : CfgBase {
     static constexpr int A = A_, L = L_, E = A_ + L_;
     static constexpr int DIM_C = 0, S = 0, N_ACT = A_;
     static constexpr int OBS_DIM = 4 + 2 * L_ + 2 * (A_ - 1);
@@ -64,7 +73,7 @@ struct SpreadCfg {
 
     // reward() :83-108 and benchmark_data() :58-74
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int*, const P& p, T* rew, bool want_info, int* info_i, T* info_f) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int*, const P& p, T* rew, bool want_info, int* info_i, T* info_f) {
         T prox = T(0), min_dists = T(0);
         int occupied = 0;
 #pragma unroll
@@ -103,7 +112,7 @@ struct SpreadCfg {
 // ------------------------------------------------------------------------------------------
 // simple_tag: 3 adversaries, 1 good agent, 2 obstacles (multiagent/scenarios/simple_tag.py)
 // ------------------------------------------------------------------------------------------
-struct TagCfg {
+struct TagCfg : CfgBase {
     static constexpr int N_ADV = 3, A = 4, L = 2, E = 6;
     static constexpr int DIM_C = 0, S = 0, N_ACT = 4;
     static constexpr int OBS_ADV = 4 + 2 * L + 2 * (A - 1) + 2, OBS_GOOD = 4 + 2 * L + 2 * (A - 1);
@@ -138,7 +147,7 @@ struct TagCfg {
 
     // reward() :84-129 and benchmark_data() :57-66
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int*, const P& p, T* rew, bool want_info, int* info_i, T*) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int*, const P& p, T* rew, bool want_info, int* info_i, T*) {
         bool hit[A][N_ADV];   // hit[g][a]: good agent g touches adversary a
         T adv_rew = T(0);
 #pragma unroll
@@ -175,7 +184,7 @@ struct TagCfg {
 // simple_world_comm: 4 adversaries (agent 0 leads and speaks), 2 good agents; landmarks
 // [obstacle, food0, food1, forest0, forest1] (multiagent/scenarios/simple_world_comm.py:52-53)
 // ------------------------------------------------------------------------------------------
-struct WorldCommCfg {
+struct WorldCommCfg : CfgBase {
     static constexpr int N_ADV = 4, A = 6, L = 5, E = 11;
     static constexpr int DIM_C = 4, S = 1, N_ACT = 7;
     static constexpr int FOOD0 = A + 1, N_FOOD = 2, FOREST0 = A + 3;
@@ -244,7 +253,7 @@ struct WorldCommCfg {
 
     // reward() :142-198 and benchmark_data() :115-123; info also carries the integer masks.
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int*, const P& p, T* rew, bool want_info, int* info_i, T*) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int*, const P& p, T* rew, bool want_info, int* info_i, T*) {
         bool hit[A][N_ADV];
 #pragma unroll
         for (int g = N_ADV; g < A; ++g)
@@ -323,7 +332,7 @@ template <typename T> __device__ __forceinline__ T sq2(T dx, T dy) { return dx *
 // ------------------------------------------------------------------------------------------
 // simple: one agent, one landmark, nothing collides (multiagent/scenarios/simple.py)
 // ------------------------------------------------------------------------------------------
-struct SimpleCfg {
+struct SimpleCfg : CfgBase {
     static constexpr int A = 1, L = 1, E = 2;
     static constexpr int DIM_C = 0, S = 0, N_ACT = 1;
     static constexpr int OBS_TOTAL = 2 + 2 * L;
@@ -340,7 +349,7 @@ struct SimpleCfg {
 
     // reward(), simple.py:41-43
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int*, const P&, T* rew, bool, int*, T*) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int*, const P&, T* rew, bool, int*, T*) {
         rew[0] = -sq2<T>(pos[0].x - pos[1].x, pos[0].y - pos[1].y);
     }
 };
@@ -349,7 +358,7 @@ struct SimpleCfg {
 // simple_adversary: agent 0 is the adversary, 2 good agents, 2 landmarks of which aux[0] is the
 // goal; nothing collides (multiagent/scenarios/simple_adversary.py)
 // ------------------------------------------------------------------------------------------
-struct AdversaryCfg {
+struct AdversaryCfg : CfgBase {
     static constexpr int N_ADV = 1, A = 3, L = 2, E = 5;
     static constexpr int DIM_C = 0, S = 0, N_ACT = 3;            // world.dim_c = 2 but every agent is silent
     static constexpr int OBS_ADV = 2 * L + 2 * (A - 1), OBS_GOOD = 2 + OBS_ADV;
@@ -379,7 +388,7 @@ struct AdversaryCfg {
 
     // reward() :76-116 (shaped branches) and benchmark_data() :56-65
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int* aux, const P&, T* rew, bool want_info, int* info_i, T* info_f) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int* aux, const P&, T* rew, bool want_info, int* info_i, T* info_f) {
         const V2<T> g = goal_of<T, E, A, L>(pos, aux[0]);
         T sq[A];
 #pragma unroll
@@ -413,7 +422,7 @@ struct AdversaryCfg {
 // simple_push: agent 0 is the adversary, agent 1 the good agent (they collide), 2 landmarks of which
 // aux[0] is the goal (multiagent/scenarios/simple_push.py)
 // ------------------------------------------------------------------------------------------
-struct PushCfg {
+struct PushCfg : CfgBase {
     static constexpr int N_ADV = 1, A = 2, L = 2, E = 4;
     static constexpr int DIM_C = 0, S = 0, N_ACT = 2;
     static constexpr int OBS_ADV = 2 + 2 * L + 2 * (A - 1), OBS_GOOD = 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1);
@@ -456,7 +465,7 @@ struct PushCfg {
 
     // reward() :55-73
     template <typename T, class P>
-    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const int* aux, const P&, T* rew, bool, int*, T*) {
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int* aux, const P&, T* rew, bool, int*, T*) {
         const V2<T> g = goal_of<T, E, A, L>(pos, aux[0]);
         T d[A];
 #pragma unroll
@@ -468,6 +477,151 @@ struct PushCfg {
         for (int i = 0; i < A; ++i) {
             // adversary: goal - agent, same squares as agent - goal
             rew[i] = adversary(i) ? dmin - d[i] : -d[i];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// simple_speaker_listener: agent 0 speaks (dim_c 3) and cannot move, agent 1 moves and is silent;
+// aux[0] is the landmark the listener should reach (agents[0].goal_b); rewards are shared
+// (multiagent/scenarios/simple_speaker_listener.py)
+// ------------------------------------------------------------------------------------------
+struct SpeakerListenerCfg : CfgBase {
+    static constexpr int A = 2, L = 3, E = 5;
+    static constexpr int DIM_C = 3, S = 1, N_ACT = 2;       // [speaker's word, listener's move]
+    static constexpr int OBS_TOTAL = 3 + (2 + 2 * L + DIM_C);
+    static constexpr int NI = 1, NF = A, N_AUX = 1;          // info: goal index; the agents' own rewards
+    static constexpr bool SHARED = true;                     // :11
+    __host__ __device__ static constexpr bool collides(int) { return false; }   // :16,26
+    __host__ __device__ static constexpr bool movable(int i) { return i == 1; } // :19
+    __host__ __device__ static constexpr bool speaks(int i) { return i == 0; }  // :21
+
+    // observation() :69-91.  Landmark l is 0.15 grey with channel l at 0.65 (reset_world :45-47).
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const int* aux, const P&, T* row) {
+        int k = 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) row[k++] = (ch == aux[0]) ? (T)0.65 : (T)0.15;      // speaker: goal colour
+        row[k++] = vel[1].x; row[k++] = vel[1].y;                                          // listener
+#pragma unroll
+        for (int l = 0; l < L; ++l) { row[k++] = pos[A + l].x - pos[1].x; row[k++] = pos[A + l].y - pos[1].y; }
+#pragma unroll
+        for (int c = 0; c < DIM_C; ++c) row[k++] = comm[c];
+    }
+
+    // reward() :63-67: both agents get minus the squared listener-goal distance
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int* aux, const P&, T* rew, bool want_info, int* info_i, T* info_f) {
+        const V2<T> g = goal_of<T, E, A, L>(pos, aux[0]);
+        const T r = -sq2<T>(pos[1].x - g.x, pos[1].y - g.y);
+        rew[0] = r; rew[1] = r;
+        if (want_info) { info_i[0] = aux[0]; info_f[0] = r; info_f[1] = r; }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// simple_reference: two agents that both move and speak (dim_c 10); aux[i] is the landmark agent i
+// wants the other agent to reach (goal_b); rewards are shared (multiagent/scenarios/simple_reference.py)
+// ------------------------------------------------------------------------------------------
+struct ReferenceCfg : CfgBase {
+    static constexpr int A = 2, L = 3, E = 5;
+    static constexpr int DIM_C = 10, S = 2, N_ACT = 4;      // [move 0, word 0, move 1, word 1]
+    static constexpr int BITS = 4;
+    static constexpr int OBS_DIM = 2 + 2 * L + 3 + DIM_C, OBS_TOTAL = A * OBS_DIM;
+    static constexpr int NI = 2, NF = A, N_AUX = 2;
+    static constexpr bool SHARED = true;                     // :10
+    __host__ __device__ static constexpr bool collides(int) { return false; }   // :15,20
+    __host__ __device__ static constexpr bool speaks(int) { return true; }
+
+    // observation() :61-80.  Landmark l is 0.25 grey with channel l at 0.75 (reset_world :40-42).
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const int* aux, const P&, T* row) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            row[k++] = vel[i].x; row[k++] = vel[i].y;
+#pragma unroll
+            for (int l = 0; l < L; ++l) { row[k++] = pos[A + l].x - pos[i].x; row[k++] = pos[A + l].y - pos[i].y; }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) row[k++] = (ch == aux[i]) ? (T)0.75 : (T)0.25;
+#pragma unroll
+            for (int c = 0; c < DIM_C; ++c) row[k++] = comm[(1 - i) * DIM_C + c];
+        }
+    }
+
+    // reward() :55-59: minus the squared distance of the other agent (goal_a) to this agent's landmark
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int* aux, const P&, T* rew, bool want_info, int* info_i, T* info_f) {
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            const V2<T> g = goal_of<T, E, A, L>(pos, aux[i]);
+            rew[i] = -sq2<T>(pos[1 - i].x - g.x, pos[1 - i].y - g.y);
+            if (want_info) { info_i[i] = aux[i]; info_f[i] = rew[i]; }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// simple_crypto: adversary Eve (agent 0), listener Bob (1), speaker Alice (2); nobody moves,
+// everybody speaks (dim_c 4); aux[0] is the goal landmark, aux[1] the landmark whose colour is
+// Alice's key; landmark l's colour is the one-hot e_l (multiagent/scenarios/simple_crypto.py)
+// ------------------------------------------------------------------------------------------
+struct CryptoCfg : CfgBase {
+    static constexpr int A = 3, L = 2, E = 5;
+    static constexpr int DIM_C = 4, S = 3, N_ACT = 3;
+    static constexpr int OBS_TOTAL = DIM_C + 2 * DIM_C + 2 * DIM_C;
+    static constexpr int NI = 2, NF = A * 2 * DIM_C, N_AUX = 2;
+    __host__ __device__ static constexpr bool collides(int) { return false; }   // :32,40
+    __host__ __device__ static constexpr bool movable(int) { return false; }    // :35
+    __host__ __device__ static constexpr bool speaks(int) { return true; }
+    static constexpr int SPEAKER = 2;                                           // :34
+
+    // observation() :124-169: Eve hears Alice; Bob gets the key and hears Alice; Alice gets goal and key
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&)[E], const V2<T> (&)[A], const T* comm, const int* aux, const P&, T* row) {
+        int k = 0;
+#pragma unroll
+        for (int c = 0; c < DIM_C; ++c) row[k++] = comm[SPEAKER * DIM_C + c];
+#pragma unroll
+        for (int c = 0; c < DIM_C; ++c) row[k++] = (c == aux[1]) ? T(1) : T(0);
+#pragma unroll
+        for (int c = 0; c < DIM_C; ++c) row[k++] = comm[SPEAKER * DIM_C + c];
+#pragma unroll
+        for (int c = 0; c < DIM_C; ++c) row[k++] = (c == aux[0]) ? T(1) : T(0);
+#pragma unroll
+        for (int c = 0; c < DIM_C; ++c) row[k++] = (c == aux[1]) ? T(1) : T(0);
+    }
+
+    // reward() :94-121 and benchmark_data() :78-80 (per agent: state.c, then the goal colour)
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&)[E], const T* comm, const int* aux, const P&, T* rew, bool want_info, int* info_i, T* info_f) {
+        T err[2];
+        bool spoke[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {       // Eve and Bob
+            err[i] = T(0);
+            spoke[i] = false;
+#pragma unroll
+            for (int c = 0; c < DIM_C; ++c) {
+                const T d = comm[i * DIM_C + c] - ((c == aux[0]) ? T(1) : T(0));
+                err[i] = err[i] + d * d;
+                spoke[i] = spoke[i] || (comm[i * DIM_C + c] != T(0));
+            }
+        }
+        const T good_rew = spoke[1] ? T(0) - err[1] : T(0);
+        const T adv_rew = spoke[0] ? T(0) + err[0] : T(0);
+        rew[0] = spoke[0] ? T(0) - err[0] : T(0);
+        rew[1] = adv_rew + good_rew;
+        rew[2] = adv_rew + good_rew;
+        if (want_info) {
+            info_i[0] = aux[0]; info_i[1] = aux[1];
+#pragma unroll
+            for (int i = 0; i < A; ++i)
+#pragma unroll
+                for (int c = 0; c < DIM_C; ++c) {
+                    info_f[i * 2 * DIM_C + c] = comm[i * DIM_C + c];
+                    info_f[i * 2 * DIM_C + DIM_C + c] = (c == aux[0]) ? T(1) : T(0);
+                }
         }
     }
 };

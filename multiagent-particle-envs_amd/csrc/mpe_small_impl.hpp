@@ -1,4 +1,5 @@
-// Fused step kernels for the small scenarios (simple_spread 3/3, simple_tag, simple_world_comm).
+// Fused step kernels for the small scenarios (simple_spread 3/3, simple_tag, simple_world_comm and the
+// other classic scenarios with a handful of entities).
 //
 // One lane owns one world and keeps its whole state in registers: it decodes the int actions,
 // runs World.step (action force, pairwise contact force, integration, comm state) and evaluates
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                                                    T* __restrict__ info_f_g, int* __restrict__ aux_g, int n_steps) {
     constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
     constexpr int NI = Cfg::NI > 0 ? Cfg::NI : 1, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C, NX = Cfg::N_AUX;
+    constexpr int NC = Cfg::S * Cfg::DIM_C;      // comm state values: the speakers' utterances in agent order
     constexpr bool LIN = ((OT * (int)sizeof(T) / 4) % 16) != 0;
     using ObsTile = Tile<T, OT, LIN, EPW>;
     using RewTile = Tile<T, A, true, EPW>;
@@ -108,16 +110,18 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     const long long b = valid ? env0 + lane : env0;   // idle tail lanes shadow the wave's first env
 
     STAMP(0);
-    // Actions are fetched NP * CH steps at a time and packed 3 bits each into NP 128-bit shift
+    // Actions are fetched NP * CH steps at a time and packed BITS (3 or 4) bits each into NP 128-bit shift
     // registers, so the step loop itself issues no loads: memory operations retire in issue order,
     // and a load issued between two steps' store bursts is only served after every older store has
     // drained (about 4 us in mid-launch).  NP is as many registers as the usual 25-step episode needs,
     // within a budget of 84 loaded words held at once (more costs occupancy in large batches).  The
     // first fetch is issued before the state is set up, so that its latency overlaps the reset
-    // draws, and all loads of a fetch are issued before any is consumed.  Move ints outside 0..7 are
-    // no-ops like any value outside 1..4 (environment.py:178-181); a comm int outside 0..7 selects
-    // no word.
-    constexpr int ABITS = 3 * NA;
+    // draws, and all loads of a fetch are issued before any is consumed.  Ints beyond the kept bits
+    // saturate: a move outside 1..4 is a no-op anyway (environment.py:178-181) and a comm int outside
+    // 0..dim_c-1 selects no word.  Columns follow the reference's action_n: per agent its move (if it is
+    // movable), then its comm word (if it speaks).
+    constexpr int BITS = Cfg::BITS, ABITS = BITS * NA;
+    constexpr unsigned AMASK = (1u << BITS) - 1u;
     constexpr int CH = (MODE == MODE_ROLLOUT) ? (128 / ABITS) : 1;
     constexpr int NP_EPISODE = (25 + CH - 1) / CH, NP_BUDGET = 84 / (CH * NA) > 0 ? 84 / (CH * NA) : 1;
     constexpr int NP = (MODE == MODE_ROLLOUT) ? (NP_EPISODE < NP_BUDGET ? NP_EPISODE : NP_BUDGET) : 1;
@@ -144,17 +148,10 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             fetched[q] = 0;
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                int col = 0;
 #pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    const unsigned mv = raw[q * CH + k][col];
-                    fetched[q] |= (unsigned __int128)(mv < 7u ? mv : 7u) << (k * ABITS + 3 * col);     // 5, 6, 7: no move
-                    ++col;
-                    if (Cfg::speaks(i)) {
-                        const unsigned wd = raw[q * CH + k][col];
-                        fetched[q] |= (unsigned __int128)(wd < 7u ? wd : 7u) << (k * ABITS + 3 * col);
-                        ++col;
-                    }
+                for (int col = 0; col < NA; ++col) {
+                    const unsigned v = raw[q * CH + k][col];
+                    fetched[q] |= (unsigned __int128)(v < AMASK ? v : AMASK) << (k * ABITS + BITS * col);
                 }
             }
         }
@@ -162,14 +159,15 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     if (MODE != MODE_OBSERVE && n_steps > 0) load_actions(0);
     V2<T> pos[E];
     V2<T> vel[A];
-    T comm[DC > 0 ? DC : 1];
+    T comm[NC > 0 ? NC : 1];
     int aux[NX > 0 ? NX : 1] = {0};
-    if (NX > 0) {      // goal landmark: drawn with the reset, otherwise the caller's
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {      // goal landmark(s): drawn with the reset, otherwise the caller's
         if (MODE == MODE_ROLLOUT && rs.enabled) {
-            aux[0] = reset_goal(rs, (unsigned long long)b, Cfg::L);
-            if (valid) aux_g[b] = aux[0];
+            aux[k] = reset_aux(rs, (unsigned long long)b, k, Cfg::L);
+            if (valid) aux_g[(long long)k * B + b] = aux[k];
         } else {
-            aux[0] = aux_g[b];
+            aux[k] = aux_g[(long long)k * B + b];
         }
     }
     if (MODE == MODE_ROLLOUT && rs.enabled) {
@@ -200,9 +198,9 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             vel[i].y = vel_g[(long long)(2 * i + 1) * B + b];
         }
     }
-    if (DC > 0) {
+    if (NC > 0) {
 #pragma unroll
-        for (int c = 0; c < DC; ++c) comm[c] = (MODE == MODE_OBSERVE) ? comm_g[(long long)c * B + b] : T(0);
+        for (int c = 0; c < NC; ++c) comm[c] = (MODE == MODE_OBSERVE) ? comm_g[(long long)c * B + b] : T(0);
     }
     constexpr bool want_info = INFO;
 
@@ -227,17 +225,22 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             packed >>= ABITS;
             int act[NA];
 #pragma unroll
-            for (int j = 0; j < NA; ++j) act[j] = (int)((cur >> (3 * j)) & 7u);
+            for (int j = 0; j < NA; ++j) act[j] = (int)((cur >> (BITS * j)) & AMASK);
             // ---- MultiAgentEnv._set_action: int actions -> forces and comm one-hot ----
             V2<T> force[A];
-            int col = 0;
+            int col = 0, slot = 0;
 #pragma unroll
             for (int i = 0; i < A; ++i) {
-                force[i] = decode_move<T>(act[col++], p.sens[i]);     // apply_action_force: u + 0
+                if (Cfg::movable(i)) {
+                    force[i] = decode_move<T>(act[col++], p.sens[i]);     // apply_action_force: u + 0
+                } else {
+                    force[i].x = T(0); force[i].y = T(0);
+                }
                 if (Cfg::speaks(i)) {
                     const int word = act[col++];
 #pragma unroll
-                    for (int c = 0; c < DC; ++c) comm[c] = (word == c) ? T(1) : T(0);   // update_agent_state
+                    for (int c = 0; c < DC; ++c) comm[slot * DC + c] = (word == c) ? T(1) : T(0);   // update_agent_state
+                    ++slot;
                 }
             }
             // ---- World.apply_environment_force: pairs in the reference's (a, b) order ----
@@ -246,16 +249,17 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 #pragma unroll
                 for (int c = a + 1; c < E; ++c) {
                     if (!Cfg::collides(a) || !Cfg::collides(c)) continue;
-                    if (a >= A && c >= A) continue;   // neither entity moves
+                    const bool ma = a < A && Cfg::movable(a), mc = c < A && Cfg::movable(c);
+                    if (!ma && !mc) continue;         // neither entity moves
                     const V2<T> f = contact_force<T>(pos[a], pos[c], p.size[a] + p.size[c], p.contact_force, p.contact_margin);
-                    if (a < A) { force[a].x = f.x + force[a].x; force[a].y = f.y + force[a].y; }
-                    if (c < A) { force[c].x = -f.x + force[c].x; force[c].y = -f.y + force[c].y; }
+                    if (ma) { force[a].x = f.x + force[a].x; force[a].y = f.y + force[a].y; }
+                    if (mc) { force[c].x = -f.x + force[c].x; force[c].y = -f.y + force[c].y; }
                 }
             }
             // ---- World.integrate_state ----
 #pragma unroll
             for (int i = 0; i < A; ++i)
-                integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[i], p.max_speed[i], p.one_minus_damping, p.dt);
+                if (Cfg::movable(i)) integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[i], p.max_speed[i], p.one_minus_damping, p.dt);
         }
 
         // ---- scenario callbacks into the wave's LDS tiles ----
@@ -263,7 +267,18 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
         bool finished = false;
         if (EPW == 64 || lane < EPW) {
             if (want_score)
-                Cfg::template score<T>(pos, aux, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
+                Cfg::template score<T>(pos, comm, aux, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
+            if (Cfg::SHARED && MODE != MODE_OBSERVE) {
+                // collaborative world: step hands every agent np.sum(reward_n) (environment.py:103-105),
+                // the first reward plus the running sum of the others
+                T* rrow = RewTile::row(tile_rew, tile_lane);
+                T rest = rrow[A > 1 ? 1 : 0];
+#pragma unroll
+                for (int i = 2; i < A; ++i) rest = rest + rrow[i];
+                const T total = A > 1 ? rrow[0] + rest : rrow[0];
+#pragma unroll
+                for (int i = 0; i < A; ++i) rrow[i] = total;
+            }
             if (MODE == MODE_STEP && au.step_count != nullptr) {
                 // ---- episode bookkeeping (mpe_step_auto): returns, step counter, time-limit reset ----
                 T* ep = (T*)au.ep_return + b * A;
@@ -293,13 +308,14 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
 #pragma unroll
                     for (int i = 0; i < A; ++i) { vel[i].x = T(0); vel[i].y = T(0); }
-                    if (DC > 0) {
+                    if (NC > 0) {
 #pragma unroll
-                        for (int c = 0; c < DC; ++c) comm[c] = T(0);
+                        for (int c = 0; c < NC; ++c) comm[c] = T(0);
                     }
-                    if (NX > 0) {
-                        aux[0] = reset_goal(nr, (unsigned long long)b, Cfg::L);
-                        if (valid) aux_g[b] = aux[0];
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) {
+                        aux[k] = reset_aux(nr, (unsigned long long)b, k, Cfg::L);
+                        if (valid) aux_g[(long long)k * B + b] = aux[k];
                     }
                     if (valid) {
 #pragma unroll
@@ -339,9 +355,9 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             vel_g[(long long)(2 * i) * B + b] = vel[i].x;
             vel_g[(long long)(2 * i + 1) * B + b] = vel[i].y;
         }
-        if (DC > 0) {
+        if (NC > 0) {
 #pragma unroll
-            for (int c = 0; c < DC; ++c) comm_g[(long long)c * B + b] = comm[c];
+            for (int c = 0; c < NC; ++c) comm_g[(long long)c * B + b] = comm[c];
         }
     }
 }
@@ -430,6 +446,12 @@ hipError_t launch_small_t(const HostSpec& s, long long B, int mode, const StepAr
             return launch_cfg<T, AdversaryCfg, true>(s, B, mode, a, st);
         case MPE_SCN_PUSH:
             return launch_cfg<T, PushCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_SPEAKER_LISTENER:
+            return launch_cfg<T, SpeakerListenerCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_REFERENCE:
+            return launch_cfg<T, ReferenceCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_CRYPTO:
+            return launch_cfg<T, CryptoCfg, true>(s, B, mode, a, st);
     }
     return hipErrorInvalidValue;
 }

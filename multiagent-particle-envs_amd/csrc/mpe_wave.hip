@@ -100,6 +100,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     // below exp(-60) = 9e-27 beyond 60 k, i.e. a force under 1e-27.
     const T cut = (sizeof(T) == 4 ? T(18) : T(60)) * p.contact_margin;
     const bool i_collide = tb->collide[me] != 0;
+    const bool i_move = tb->movable[me] != 0;       // an immovable agent keeps its state (core.py:195)
     const T my_size = size_s[me];
     const T my_mass = (T)tb->mass[me];
     const T my_sens = (T)tb->sens[me];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
         const long long row = (long long)t * B + b;
         if (MODE != WMODE_OBSERVE) {
             V2<T> pi = P[me], vi = Vel[me];
-            if (is_agent) {             // a wave without agents goes straight to the barrier
+            if (is_agent && i_move) {   // a wave without agents goes straight to the barrier
                 // ---- action force ----
                 V2<T> f;
                 if (EPI == EPI_SPREAD) {

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "libmpe_hip.so")
 
 MPE_F32, MPE_F64 = 0, 1
 SCN_NONE, SCN_SPREAD, SCN_TAG, SCN_WORLD_COMM, SCN_SIMPLE, SCN_ADVERSARY, SCN_PUSH = 0, 1, 2, 3, 4, 5, 6
+SCN_SPEAKER_LISTENER, SCN_REFERENCE, SCN_CRYPTO = 7, 8, 9
 MAX_AGENTS = 64
 MAX_LANDMARKS = 64
 MAX_WALLS = 16
@@ -27,7 +28,7 @@ class MpeSpec(C.Structure):
         ("dt", C.c_double), ("damping", C.c_double), ("contact_force", C.c_double), ("contact_margin", C.c_double),
         ("size", _p_f64), ("mass", _p_f64), ("movable", _p_u8), ("collide", _p_u8),
         ("sensitivity", _p_f64), ("max_speed", _p_f64), ("silent", _p_u8), ("adversary", _p_u8), ("leader", _p_u8),
-        ("n_walls", C.c_int32), ("reserved", C.c_int32),
+        ("n_walls", C.c_int32), ("collaborative", C.c_int32),
         ("wall_vertical", _p_u8), ("wall_axis_pos", _p_f64), ("wall_end0", _p_f64), ("wall_end1", _p_f64),
         ("wall_width", _p_f64), ("wall_hard", _p_u8), ("ghost", _p_u8),
     ]

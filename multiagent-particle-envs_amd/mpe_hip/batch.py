@@ -24,12 +24,15 @@ class BatchedEnv:
     Tensors (T = float32 or float64):
       pos   [2E, B]  env-minor entity coordinates (agents first)     vel  [2A, B]
       comm  [S*dim_c, B] comm state of the S speaking agents (or None)
-      aux   [n_aux, B] int32: the goal landmark index of simple_adversary / simple_push (or None)
+      aux   [n_aux, B] int32: the landmark indices reset_world draws (goal landmark; goal_b of both agents in
+            simple_reference; goal and key in simple_crypto), or None
       (worlds simulated by a whole wave -- ``env_major`` is True -- store these transposed:
       pos [B, 2E], vel [B, 2A], comm [B, S*dim_c]; use get_state / set_state to stay layout-agnostic)
       obs   [B, obs_total]; ``obs_n[i]`` is the view of agent i's columns
       rew   [B, A]    done [B] uint8    info_i [B, n_info_i] int32    info_f [B, n_info_f]
-    Actions are int32 ``[B, n_act]``: per agent its move 0..4, then its comm word if it speaks.
+    Actions are int32 ``[B, n_act]``: per agent its move 0..4 if it is movable, then its comm word if it speaks.
+    In a collaborative world (simple_speaker_listener, simple_reference) ``rew`` holds the shared reward as
+    ``MultiAgentEnv.step`` returns it; the agents' own rewards are in ``info_f``.
     """
 
     def __init__(self, scenario, n_envs, dtype=torch.float32, device="cuda:0", info=False, max_episode_steps=None, seed=0,
@@ -179,8 +182,8 @@ class BatchedEnv:
 
     # ------------------------------------------------------------------
     def set_state(self, pos, vel, comm=None, goal=None):
-        """Inject a state given env-major: pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c], and the goal
-        landmark index [B] of scenarios that have one (kept when None)."""
+        """Inject a state given env-major: pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c], and the landmark
+        indices reset_world draws, [B] or [B, n_aux], of scenarios that have them (kept when None)."""
         B, A, L = self.n_envs, self.n_agents, self.n_landmarks
         lay = (lambda x: x.contiguous()) if self.env_major else (lambda x: x.t().contiguous())
         pos = torch.as_tensor(np.asarray(pos), dtype=self.dtype).reshape(B, 2 * (A + L))
@@ -195,7 +198,7 @@ class BatchedEnv:
         if goal is not None:
             if self.aux is None:
                 raise ValueError("this scenario has no goal landmark")
-            self.aux[0].copy_(torch.as_tensor(np.asarray(goal), dtype=torch.int32).reshape(B))
+            self.aux.copy_(torch.as_tensor(np.asarray(goal), dtype=torch.int32).reshape(B, self.aux.shape[0]).t())
 
     def get_state(self):
         """Returns env-major numpy copies (pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c] or None)."""
@@ -208,8 +211,11 @@ class BatchedEnv:
 
     @property
     def goal(self):
-        """Goal landmark index per env ([B] int32 view), for scenarios that draw one at reset."""
-        return None if self.aux is None else self.aux[0]
+        """Landmark indices drawn at reset: a [B] int32 view for scenarios with one goal landmark,
+        [B, n_aux] for those with two."""
+        if self.aux is None:
+            return None
+        return self.aux[0] if self.aux.shape[0] == 1 else self.aux.t()
 
     def world_step(self, u, c=None):
         """World.step alone (multiagent/core.py:142-158) for a physics-only handle (scenario id

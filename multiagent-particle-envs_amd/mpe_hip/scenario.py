@@ -31,7 +31,7 @@ def spec_from_world(world, scenario_id, name):
                      adversary=np.array([bool(getattr(a, "adversary", False)) for a in ag]),
                      leader=np.array([bool(getattr(a, "leader", False)) for a in ag]),
                      dt=world.dt, damping=world.damping, contact_force=world.contact_force,
-                     contact_margin=world.contact_margin, name=name)
+                     contact_margin=world.contact_margin, name=name, collaborative=bool(getattr(world, "collaborative", False)))
 
 
 class HipScenario(BaseScenario):
@@ -43,6 +43,7 @@ class HipScenario(BaseScenario):
     hip_name = ""
     obs_dtype = np.float64
     has_info = True          # the scenario defines benchmark_data
+    fused_info = None        # ask the kernel for info_i / info_f (None: when has_info)
 
     def __init__(self):
         self._env = None        # (signature, BatchedEnv)
@@ -52,27 +53,33 @@ class HipScenario(BaseScenario):
     def fused_env(self, world):
         from . import BatchedEnv
         import torch
-        sig = world._signature() + (tuple(bool(getattr(a, "adversary", False)) for a in world.agents),)
+        sig = world._signature() + (tuple(bool(getattr(a, "adversary", False)) for a in world.agents),
+                                    bool(getattr(world, "collaborative", False)))
         if self._env is None or self._env[0] != sig:
             spec = spec_from_world(world, self.scenario_id, self.hip_name)
-            self._env = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=world.device, info=self.has_info))
+            want_info = self.has_info if self.fused_info is None else self.fused_info
+            self._env = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=world.device, info=want_info))
             self._cache = None
         return self._env[1]
 
-    @staticmethod
-    def goal_index(world):
-        """Index of the goal landmark the agents share (``agent.goal_a``), or None."""
+    def goal_index(self, world):
+        """Landmark indices reset_world drew for the episode: an int (the goal landmark the agents
+        share, ``agent.goal_a``), a list of ints, or None."""
         g = getattr(world.agents[0], "goal_a", None)
         return None if g is None else world.landmarks.index(g)
 
     @staticmethod
     def _key(pos, vel, comm, goal):
-        return pos.tobytes() + vel.tobytes() + (comm.tobytes() if comm is not None else b"") + bytes([255 if goal is None else goal])
+        return pos.tobytes() + vel.tobytes() + (comm.tobytes() if comm is not None else b"") + \
+            bytes([255] if goal is None else np.atleast_1d(goal).tolist())
 
     @staticmethod
     def _outputs(env):
+        """(obs, rew, info_i, info_f) of the one world; rew holds what the reward callback returns, so in
+        a collaborative world the agents' own rewards (info_f) rather than the shared sum a step leaves in rew."""
         np_ = lambda t: None if t is None else t[0].cpu().numpy()
-        return env.obs[0].cpu().numpy(), env.rew[0].cpu().numpy(), np_(env.info_i), np_(env.info_f)
+        rew = np_(env.info_f)[:env.n_agents] if env.spec.collaborative else env.rew[0].cpu().numpy()
+        return env.obs[0].cpu().numpy(), rew, np_(env.info_i), np_(env.info_f)
 
     def load_state(self, world, env):
         """Copy the world's state (and goal landmark) into the one-world batch."""

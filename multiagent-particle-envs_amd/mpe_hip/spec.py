@@ -34,6 +34,8 @@ class WorldSpec:
     # Agent.ghost flags.  Only the physics-only step (SCN_NONE) simulates walls.
     walls: list = field(default_factory=list)
     ghost: np.ndarray = None
+    # World.collaborative: step returns the summed reward to every agent (multiagent/environment.py:38,103-105)
+    collaborative: bool = False
 
     def to_c(self):
         """Returns (MpeSpec, keepalive) -- keepalive owns the arrays the struct points into."""
@@ -52,7 +54,7 @@ class WorldSpec:
             arrs["ghost"] = u8(self.ghost, A)
         s = _lib.MpeSpec(scenario=self.scenario, n_agents=A, n_landmarks=self.n_landmarks, dim_c=self.dim_c,
                          dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin,
-                         n_walls=W)
+                         n_walls=W, collaborative=int(bool(self.collaborative)))
         for k, a in arrs.items():
             ptr_t = _lib._p_f64 if a.dtype == np.float64 else _lib._p_u8
             setattr(s, k, a.ctypes.data_as(ptr_t))
@@ -127,6 +129,34 @@ def push_spec():
                      adversary=adv, leader=np.zeros(2, bool), name="simple_push")
 
 
+def speaker_listener_spec():
+    """simple_speaker_listener (multiagent/scenarios/simple_speaker_listener.py:6-31): agent 0 speaks
+    (dim_c 3) and cannot move, agent 1 moves and is silent, both of size 0.075; 3 landmarks of size
+    0.04; nothing collides; rewards are shared."""
+    return WorldSpec(_lib.SCN_SPEAKER_LISTENER, 2, 3, 3, size=np.r_[np.full(2, 0.075), np.full(3, 0.04)], mass=np.ones(5),
+                     movable=np.array([False, True, False, False, False]), collide=np.zeros(5, bool),
+                     sensitivity=np.full(2, 5.0), max_speed=np.full(2, np.inf), silent=np.array([False, True]),
+                     adversary=np.zeros(2, bool), leader=np.zeros(2, bool), name="simple_speaker_listener", collaborative=True)
+
+
+def reference_spec():
+    """simple_reference (multiagent/scenarios/simple_reference.py:6-24): two agents that both move and
+    speak (dim_c 10), 3 landmarks, default sizes, nothing collides; rewards are shared."""
+    return WorldSpec(_lib.SCN_REFERENCE, 2, 3, 10, size=np.full(5, 0.05), mass=np.ones(5),
+                     movable=np.r_[np.ones(2, bool), np.zeros(3, bool)], collide=np.zeros(5, bool),
+                     sensitivity=np.full(2, 5.0), max_speed=np.full(2, np.inf), silent=np.zeros(2, bool),
+                     adversary=np.zeros(2, bool), leader=np.zeros(2, bool), name="simple_reference", collaborative=True)
+
+
+def crypto_spec():
+    """simple_crypto (multiagent/scenarios/simple_crypto.py:21-44): adversary Eve (agent 0), listener
+    Bob (1) and speaker Alice (2); nobody moves, everybody speaks (dim_c 4); 2 landmarks."""
+    return WorldSpec(_lib.SCN_CRYPTO, 3, 2, 4, size=np.full(5, 0.05), mass=np.ones(5),
+                     movable=np.zeros(5, bool), collide=np.zeros(5, bool),
+                     sensitivity=np.full(3, 5.0), max_speed=np.full(3, np.inf), silent=np.zeros(3, bool),
+                     adversary=np.array([True, False, False]), leader=np.zeros(3, bool), name="simple_crypto")
+
+
 def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, walls=(), ghost=None, **world):
     """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158); the
     scenario's observation / reward callbacks stay with the caller."""
@@ -151,4 +181,10 @@ def make_spec(name, **kw):
         return adversary_spec()
     if name == "simple_push":
         return push_spec()
+    if name == "simple_speaker_listener":
+        return speaker_listener_spec()
+    if name == "simple_reference":
+        return reference_spec()
+    if name == "simple_crypto":
+        return crypto_spec()
     raise ValueError("no batched kernel for scenario %r" % (name,))

@@ -143,7 +143,7 @@ class World:
                                        for w in self.walls],
                                 ghost=[getattr(a, "ghost", False) for a in self.agents],
                                 dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin)
-            spec.movable = np.array([bool(e.movable) for e in ents])     # mpe_create refuses immovable agents / movable landmarks
+            spec.movable = np.array([bool(e.movable) for e in ents])     # immovable agents keep their state; mpe_create refuses movable landmarks
             self._phys = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=self.device))
         return self._phys[1]
 

@@ -18,10 +18,13 @@ scalar code so that float64 results are bit-identical, not merely close:
 * ``vel``  float64 ``[B, A, 2]``   agent velocities (landmarks never move in scope)
 * ``comm`` float64 ``[B, A, dim_c]`` agent communication state ``state.c``
 * ``goal`` int ``[B]``             index of the goal landmark (``agent.goal_a``) in
-                                   simple_adversary / simple_push, drawn by reset_world
+                                   simple_adversary / simple_push / simple_speaker_listener
+                                   (``agents[0].goal_b``), drawn by reset_world; ``[B, 2]`` for
+                                   simple_reference (``goal_b`` of agent 0 and of agent 1) and
+                                   simple_crypto (goal landmark, key landmark)
 * ``actions`` int ``[B, n_act]``   flattened reference ``action_n`` list: for each agent
-                                   its move int 0..4, followed by its comm int if the
-                                   agent is not silent (multiagent/environment.py:173-204)
+                                   its move int 0..4 if it is movable, followed by its comm
+                                   int if it is not silent (multiagent/environment.py:173-204)
 """
 from __future__ import annotations
 
@@ -36,6 +39,9 @@ SCN_WORLD_COMM = "simple_world_comm"
 SCN_SIMPLE = "simple"
 SCN_ADVERSARY = "simple_adversary"
 SCN_PUSH = "simple_push"
+SCN_SPEAKER_LISTENER = "simple_speaker_listener"
+SCN_REFERENCE = "simple_reference"
+SCN_CRYPTO = "simple_crypto"
 
 
 @dataclass
@@ -66,6 +72,8 @@ class Spec:
     # World.walls as dicts {orient, axis_pos, endpoints, width, hard} (core.py:26-42) and Agent.ghost
     walls: List[dict] = field(default_factory=list)
     ghost: Optional[np.ndarray] = None
+    # World.collaborative: every agent receives the sum of the rewards (environment.py:103-105)
+    shared: bool = False
 
     @property
     def E(self) -> int:
@@ -73,7 +81,7 @@ class Spec:
 
     @property
     def n_act(self) -> int:
-        return int(self.A + np.count_nonzero(~self.silent))
+        return int(np.count_nonzero(self.movable[:self.A]) + np.count_nonzero(~self.silent))
 
     @property
     def obs_dims(self) -> List[int]:
@@ -101,6 +109,12 @@ class Spec:
             return [(0 if self.adversary[i] else 2) + 2 * L + 2 * (A - 1) for i in range(A)]
         if self.scenario == SCN_PUSH:
             return [2 + 2 * L + 2 * (A - 1) if self.adversary[i] else 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1) for i in range(A)]
+        if self.scenario == SCN_SPEAKER_LISTENER:
+            return [3, 2 + 2 * L + self.dim_c]
+        if self.scenario == SCN_REFERENCE:
+            return [2 + 2 * L + 3 + self.dim_c] * A
+        if self.scenario == SCN_CRYPTO:
+            return [self.dim_c, 2 * self.dim_c, 2 * self.dim_c]
         raise ValueError(self.scenario)
 
 
@@ -180,7 +194,42 @@ def spec_push() -> Spec:
                 adversary=adv, leader=np.zeros(A, bool))
 
 
+def spec_speaker_listener() -> Spec:
+    """simple_speaker_listener.make_world, multiagent/scenarios/simple_speaker_listener.py:6-31:
+    agent 0 speaks and cannot move, agent 1 moves and is silent; rewards are shared (:11)."""
+    A, L = 2, 3
+    size = np.array([0.075] * A + [0.04] * L)                              # :17, :28
+    movable = np.array([False, True] + [False] * L)                        # :19, :27
+    return Spec(SCN_SPEAKER_LISTENER, A, L, 3, size, movable, np.zeros(A + L, bool), np.ones(A + L),
+                sens=np.full(A, 5.0), max_speed=np.full(A, np.inf), silent=np.array([False, True]),   # :21
+                adversary=np.zeros(A, bool), leader=np.zeros(A, bool), shared=True)
+
+
+def spec_reference() -> Spec:
+    """simple_reference.make_world, multiagent/scenarios/simple_reference.py:6-24: two agents that
+    both move and speak (dim_c 10), default sizes, nothing collides, shared rewards (:10)."""
+    A, L = 2, 3
+    return Spec(SCN_REFERENCE, A, L, 10, np.full(A + L, 0.05), np.array([True] * A + [False] * L), np.zeros(A + L, bool),
+                np.ones(A + L), sens=np.full(A, 5.0), max_speed=np.full(A, np.inf), silent=np.zeros(A, bool),
+                adversary=np.zeros(A, bool), leader=np.zeros(A, bool), shared=True)
+
+
+def spec_crypto() -> Spec:
+    """simple_crypto.make_world, multiagent/scenarios/simple_crypto.py:21-44: adversary (Eve),
+    listener (Bob) and speaker (Alice, agent 2); nobody moves, everybody speaks (dim_c 4)."""
+    A, L = 3, 2
+    return Spec(SCN_CRYPTO, A, L, 4, np.full(A + L, 0.05), np.zeros(A + L, bool), np.zeros(A + L, bool), np.ones(A + L),
+                sens=np.full(A, 5.0), max_speed=np.full(A, np.inf), silent=np.zeros(A, bool),
+                adversary=np.array([True, False, False]), leader=np.zeros(A, bool))
+
+
 def make_spec(name: str, **kw) -> Spec:
+    if name == SCN_SPEAKER_LISTENER:
+        return spec_speaker_listener()
+    if name == SCN_REFERENCE:
+        return spec_reference()
+    if name == SCN_CRYPTO:
+        return spec_crypto()
     if name == SCN_SIMPLE:
         return spec_simple()
     if name == SCN_ADVERSARY:
@@ -207,12 +256,13 @@ def decode_actions(spec: Spec, actions: np.ndarray):
     c = np.zeros((B, spec.A, spec.dim_c))
     col = 0
     for i in range(spec.A):
-        a = actions[:, col]
-        col += 1
-        # :178-181 ; ints outside 1..4 leave u at zero
-        u[:, i, 0] = np.where(a == 1, -1.0, np.where(a == 2, 1.0, 0.0))
-        u[:, i, 1] = np.where(a == 3, -1.0, np.where(a == 4, 1.0, 0.0))
-        u[:, i, :] *= spec.sens[i]                      # :192-195
+        if spec.movable[i]:                                 # :173
+            a = actions[:, col]
+            col += 1
+            # :178-181 ; ints outside 1..4 leave u at zero
+            u[:, i, 0] = np.where(a == 1, -1.0, np.where(a == 2, 1.0, 0.0))
+            u[:, i, 1] = np.where(a == 3, -1.0, np.where(a == 4, 1.0, 0.0))
+            u[:, i, :] *= spec.sens[i]                      # :192-195
         if not spec.silent[i]:
             k = actions[:, col]
             col += 1
@@ -384,6 +434,30 @@ def observe(spec: Spec, pos, vel, comm, goal=None) -> List[np.ndarray]:
                 color[np.arange(B), np.asarray(goal) + 1] += 0.5
                 out.append(np.concatenate([vel[:, i, :], g - pos[:, i, :], color] + ent + lm_color + oth, axis=1))
         return out
+    if spec.scenario == SCN_SPEAKER_LISTENER:
+        # simple_speaker_listener.py:69-91; landmark colours of reset_world :45-47
+        color = np.full((B, 3), 0.15)
+        color[np.arange(B), np.asarray(goal)] = 0.65
+        ent = [pos[:, A + l, :] - pos[:, 1, :] for l in range(L)]
+        return [color, np.concatenate([vel[:, 1, :]] + ent + [comm[:, 0, :]], axis=1)]
+    if spec.scenario == SCN_REFERENCE:
+        # simple_reference.py:61-80; landmark colours of reset_world :40-42
+        goal = np.asarray(goal)
+        for i in range(A):
+            color = np.full((B, 3), 0.25)
+            color[np.arange(B), goal[:, i]] = 0.75
+            ent = [pos[:, A + l, :] - pos[:, i, :] for l in range(L)]
+            out.append(np.concatenate([vel[:, i, :]] + ent + [color] + [comm[:, j, :] for j in range(A) if j != i], axis=1))
+        return out
+    if spec.scenario == SCN_CRYPTO:
+        # simple_crypto.py:124-169; one-hot landmark colours of reset_world :55-59
+        goal = np.asarray(goal)
+        goal_color = np.zeros((B, spec.dim_c))
+        goal_color[np.arange(B), goal[:, 0]] = 1.0
+        key = np.zeros((B, spec.dim_c))
+        key[np.arange(B), goal[:, 1]] = 1.0
+        said = comm[:, 2, :]                                 # the speaker's utterance
+        return [said.copy(), np.concatenate([key, said], axis=1), np.concatenate([goal_color, key], axis=1)]
     if spec.scenario == SCN_SPREAD:
         # simple_spread.py:110-130 ; result cast to float32 (:130)
         for i in range(A):
@@ -457,12 +531,38 @@ def _sq(d):
     return sq[..., 0] + sq[..., 1]
 
 
-def reward(spec: Spec, pos, goal=None) -> np.ndarray:
-    """Per-agent rewards ``[B, A]`` float64 (reference mixes Python ints and
-    numpy floats; the values are equal)."""
+def reward(spec: Spec, pos, goal=None, comm=None) -> np.ndarray:
+    """Per-agent rewards ``[B, A]`` float64 as the scenario's reward callback returns them, i.e.
+    before MultiAgentEnv shares them (reference mixes Python ints and numpy floats; the values
+    are equal)."""
     A, L = spec.A, spec.L
     B = pos.shape[0]
     rew = np.zeros((B, A))
+    if spec.scenario == SCN_SPEAKER_LISTENER:
+        # simple_speaker_listener.py:63-67: listener (agents[0].goal_a) to the goal landmark
+        r = -_sq(pos[:, 1, :] - _goal_pos(spec, pos, goal))
+        rew[:, 0] = r
+        rew[:, 1] = r
+        return rew
+    if spec.scenario == SCN_REFERENCE:
+        # simple_reference.py:55-59: the other agent (goal_a) to this agent's goal landmark (goal_b)
+        goal = np.asarray(goal)
+        for i in range(A):
+            rew[:, i] = -_sq(pos[:, 1 - i, :] - _goal_pos(spec, pos, goal[:, i]))
+        return rew
+    if spec.scenario == SCN_CRYPTO:
+        # simple_crypto.py:94-121: squared error of Bob's / Eve's utterance against the goal colour;
+        # an all-zero utterance (only before the first step) is skipped
+        goal_color = np.zeros((B, spec.dim_c))
+        goal_color[np.arange(B), np.asarray(goal)[:, 0]] = 1.0
+        err = [np.square(comm[:, i, :] - goal_color).sum(axis=1) for i in range(A)]
+        spoke = [comm[:, i, :].any(axis=1) for i in range(A)]
+        good_rew = np.where(spoke[1], 0 - err[1], 0.0)       # good_listeners = [agent 1]
+        adv_rew = np.where(spoke[0], 0 + err[0], 0.0)        # adversaries = [agent 0]
+        rew[:, 0] = np.where(spoke[0], 0 - err[0], 0.0)
+        rew[:, 1] = adv_rew + good_rew
+        rew[:, 2] = adv_rew + good_rew
+        return rew
     if spec.scenario == SCN_SIMPLE:
         rew[:, 0] = -_sq(pos[:, 0, :] - pos[:, A, :])            # simple.py:41-43
         return rew
@@ -543,8 +643,11 @@ def reward(spec: Spec, pos, goal=None) -> np.ndarray:
     raise ValueError(spec.scenario)
 
 
-def info(spec: Spec, pos, goal=None):
+def info(spec: Spec, pos, goal=None, comm=None):
     """benchmark_data.  Returns dict of arrays.
+
+    simple_crypto (simple_crypto.py:78-80): ``c_goal`` [B, A, 2 * dim_c] -- per agent its utterance
+    state.c followed by the goal landmark's one-hot colour.
 
     simple_adversary (simple_adversary.py:56-65): ``sq`` -- per agent the list of
     squared distances it reports (adversary: to the goal; good: to every landmark,
@@ -557,6 +660,10 @@ def info(spec: Spec, pos, goal=None):
     """
     A, L = spec.A, spec.L
     B = pos.shape[0]
+    if spec.scenario == SCN_CRYPTO:
+        goal_color = np.zeros((B, spec.dim_c))
+        goal_color[np.arange(B), np.asarray(goal)[:, 0]] = 1.0
+        return {"c_goal": np.concatenate([comm, np.repeat(goal_color[:, None, :], A, axis=1)], axis=2)}
     if spec.scenario == SCN_ADVERSARY:
         g = _goal_pos(spec, pos, goal)
         cols = []
@@ -594,17 +701,29 @@ def info(spec: Spec, pos, goal=None):
     return {"collisions": coll}
 
 
+def share(spec: Spec, rew):
+    """environment.py:103-105: with World.collaborative every agent receives np.sum(reward_n),
+    which adds the first reward to the running sum of the others."""
+    if not spec.shared:
+        return rew
+    rest = np.zeros(rew.shape[0])
+    for i in range(1, spec.A):
+        rest = rest + rew[:, i]
+    return np.repeat((rew[:, 0] + rest)[:, None], spec.A, axis=1)
+
+
 def env_step(spec: Spec, pos, vel, actions, goal=None):
     """MultiAgentEnv.step, multiagent/environment.py:83-115, for B envs.
 
-    Returns (pos, vel, comm, obs_list, rew [B, A], done [B] bool).
+    Returns (pos, vel, comm, obs_list, rew [B, A], done [B] bool); rew is what step returns, i.e.
+    after sharing when the world is collaborative.
     ``done`` is always False: no in-scope scenario supplies a done callback
     (environment.py:143-146).
     """
     u, c = decode_actions(spec, actions)
     pos, vel, comm = world_step(spec, pos, vel, u, c)
     obs = observe(spec, pos, vel, comm, goal)
-    rew = reward(spec, pos, goal)
+    rew = share(spec, reward(spec, pos, goal, comm))
     return pos, vel, comm, obs, rew, np.zeros(pos.shape[0], bool)
 
 
@@ -632,12 +751,14 @@ def reset(spec: Spec, rng: np.random.RandomState, B: int = 1):
 
 
 def reset_with_goal(spec: Spec, rng: np.random.RandomState, B: int = 1):
-    """reset_world of simple_adversary (:35-54) / simple_push (:34-53): the goal landmark is drawn
-    first (np.random.choice over the landmark list), then the positions as in ``reset``.
-    Returns (pos, vel, comm, goal [B])."""
-    goal = np.zeros(B, np.int64)
+    """reset_world of simple_adversary (:35-54) / simple_push (:34-53) / simple_speaker_listener
+    (:33-57): the goal landmark is drawn first (np.random.choice over the landmark list), then the
+    positions as in ``reset``; simple_reference and simple_crypto draw two landmark indices.
+    Returns (pos, vel, comm, goal [B] or [B, 2])."""
+    two = spec.scenario in (SCN_REFERENCE, SCN_CRYPTO)      # simple_reference.py:33-35, simple_crypto.py:61-63
+    goal = np.zeros((B, 2) if two else B, np.int64)
     pos = np.zeros((B, spec.E, 2))
     for b in range(B):
-        goal[b] = rng.choice(spec.L)
+        goal[b] = [rng.choice(spec.L), rng.choice(spec.L)] if two else rng.choice(spec.L)
         pos[b] = reset(spec, rng, 1)[0][0]
     return pos, np.zeros((B, spec.A, 2)), np.zeros((B, spec.A, spec.dim_c)), goal

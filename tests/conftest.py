@@ -33,6 +33,10 @@ GOLDEN_CASES = {
 # simple, simple_adversary, simple_push: fixtures also hold the goal landmark index per env
 CLASSIC_CASES = ["simple", "simple_adversary", "simple_push"]
 
+# scenarios with immovable and / or speaking agents; fixtures hold the drawn landmark indices (goal),
+# the comm state, the agents' own rewards before sharing and the callbacks on the reset state
+COMM_CASES = ["simple_speaker_listener", "simple_reference", "simple_crypto"]
+
 
 @pytest.fixture(scope="session")
 def golden():

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
-from conftest import CLASSIC_CASES, GOLDEN_CASES, load_golden
+from conftest import CLASSIC_CASES, COMM_CASES, GOLDEN_CASES, load_golden
 
 
 @pytest.mark.parametrize("case", list(GOLDEN_CASES))
@@ -134,3 +134,42 @@ def test_reset_with_goal_distribution():
     pos, vel, comm, goal = orc.reset_with_goal(spec, np.random.RandomState(3), 400)
     assert set(goal) == {0, 1} and 0.35 < goal.mean() < 0.65
     assert np.abs(pos).max() <= 1.0 and not vel.any()
+
+
+@pytest.mark.parametrize("case", COMM_CASES)
+def test_oracle_reproduces_comm_scenarios(case):
+    """simple_speaker_listener / simple_crypto through the reference's MultiAgentEnv.step and
+    simple_reference through World.step + callbacks + np.sum sharing: state, comm state, observations,
+    shared and own rewards, benchmark_data and the callbacks on the reset state, bit for bit."""
+    g = load_golden(case)
+    spec = orc.make_spec(case)
+    assert spec.obs_dims == list(g["obs_dims"]) and spec.n_act == g["actions"].shape[2]
+    goal = g["goal"]
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    B = pos.shape[0]
+    comm0 = np.zeros((B, spec.A, spec.dim_c))
+    assert np.array_equal(np.concatenate(orc.observe(spec, pos, vel, comm0, goal), axis=1), g["obs0"])
+    assert np.array_equal(orc.reward(spec, pos, goal, comm0), g["rew0"])
+    for t in range(g["actions"].shape[0]):
+        pos, vel, comm, obs, rew, done = orc.env_step(spec, pos, vel, g["actions"][t], goal)
+        assert np.array_equal(pos[:, :spec.A], g["pos"][t]), (case, t)
+        assert np.array_equal(vel, g["vel"][t]), (case, t)
+        assert np.array_equal(comm[:, ~spec.silent].reshape(B, -1), g["comm"][t]), (case, t)
+        assert np.array_equal(rew, g["rew"][t]), (case, t)
+        assert np.array_equal(orc.reward(spec, pos, goal, comm), g["rew_own"][t]), (case, t)
+        assert np.array_equal(np.concatenate(obs, axis=1), g["obs"][t]), (case, t)
+        assert not done.any() and not g["done"][t].any()
+        if "info_c_goal" in g:
+            assert np.array_equal(orc.info(spec, pos, goal, comm)["c_goal"], g["info_c_goal"][t])
+    if spec.shared:
+        assert np.array_equal(g["rew"][..., 0], g["rew_own"].sum(axis=-1)) and np.array_equal(g["rew"][..., 0], g["rew"][..., 1])
+    # immovable agents never move
+    for i in range(spec.A):
+        if not spec.movable[i]:
+            assert np.array_equal(g["pos"][-1][:, i], g["pos0"][:, i])
+
+
+def test_reset_with_two_landmark_draws():
+    spec = orc.make_spec("simple_crypto")
+    pos, vel, comm, goal = orc.reset_with_goal(spec, np.random.RandomState(4), 300)
+    assert goal.shape == (300, 2) and set(goal.ravel()) == {0, 1}

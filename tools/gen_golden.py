@@ -24,6 +24,11 @@ Reference entry points used:
     ``action.u`` / ``action.c`` are written with the semantics of
     environment.py:176-201 and ``World.step`` plus the scenario callbacks are
     called directly; the other five agents go through ``_set_action``.
+  * simple_speaker_listener, simple_crypto: ``MultiAgentEnv.step`` (their agents take a single
+    int each: an immovable speaker its comm word, the silent listener its move).
+    simple_reference: both agents move and speak, so as for the simple_world_comm leader their
+    ``action.u`` / ``action.c`` are written directly and ``World.step``, the callbacks and the
+    reward sharing of environment.py:103-105 (``np.sum(reward_n)``) are called here.
   * simple_spread with 64 agents / 64 landmarks: the reference hard-codes 3/3
     (simple_spread.py:12-13); the world is assembled here from the reference's
     ``World/Agent/Landmark`` classes with the same property assignments
@@ -113,7 +118,8 @@ def load_reference():
     _load("multiagent.multi_discrete", os.path.join(REF, "multiagent", "multi_discrete.py"))
     ref.environment = _load("multiagent.environment", os.path.join(REF, "multiagent", "environment.py"))
     ref.scenarios = {}
-    for n in ("simple_spread", "simple_tag", "simple_world_comm", "simple", "simple_adversary", "simple_push"):
+    for n in ("simple_spread", "simple_tag", "simple_world_comm", "simple", "simple_adversary", "simple_push",
+              "simple_speaker_listener", "simple_reference", "simple_crypto"):
         ref.scenarios[n] = _load("ref_scn_" + n, os.path.join(REF, "multiagent", "scenarios", n + ".py"))
     return ref
 
@@ -493,6 +499,101 @@ def run_classic(ref, name, seed, B=32):
     return pos0, vel0, actions, rec
 
 
+def _move_u(m, accel):
+    """environment.py:176-181,192-195 for one int move."""
+    u = np.zeros(2)
+    if m == 1: u[0] = -1.0
+    if m == 2: u[0] = +1.0
+    if m == 3: u[1] = -1.0
+    if m == 4: u[1] = +1.0
+    return u * (accel if accel is not None else 5.0)
+
+
+def run_comm(ref, name, seed, B=32):
+    """simple_speaker_listener / simple_reference / simple_crypto.  The landmark indices reset_world
+    draws with np.random.choice (goal_b of the speaker; goal_b of both agents; goal and key) are the
+    reference's own draws, repeated until they give the indices the fixture asks for."""
+    sc = ref.scenarios[name].Scenario()
+    world = sc.make_world()
+    info_cb = sc.benchmark_data if name == "simple_crypto" else None      # the other two define none that runs
+    env = ref.environment.MultiAgentEnv(world, lambda w, rng: sc.reset_world(w), sc.reward, sc.observation, info_cb)
+    assert env.shared_reward == (name != "simple_crypto")
+    A, L, dim_c = len(world.agents), len(world.landmarks), world.dim_c
+    speakers = [i for i, a in enumerate(world.agents) if not a.silent]
+    rng = np.random.RandomState(seed)
+    pos0 = rng.uniform(-1, 1, (B, A + L, 2))
+    vel0 = np.zeros((B, A, 2))
+    vel0[B // 2:] = rng.uniform(-1, 1, (B - B // 2, A, 2))
+    for i, a in enumerate(world.agents):
+        if not a.movable:
+            vel0[:, i] = 0.0
+    n_aux = 1 if name == "simple_speaker_listener" else 2
+    aux = rng.randint(0, L, (B, n_aux))
+    cols = []
+    for a in world.agents:
+        if a.movable:
+            cols.append(rng.randint(0, 5, (T_STEPS, B)))
+        if not a.silent:
+            cols.append(rng.randint(0, dim_c, (T_STEPS, B)))
+    actions = np.stack(cols, axis=2)
+
+    def drawn():
+        lm = world.landmarks
+        if name == "simple_speaker_listener":
+            return [lm.index(world.agents[0].goal_b)]
+        if name == "simple_reference":
+            return [lm.index(world.agents[0].goal_b), lm.index(world.agents[1].goal_b)]
+        return [lm.index(world.agents[0].goal_a), int(np.argmax(world.agents[2].key))]
+
+    dims = [sp.shape[0] for sp in env.observation_space]
+    rec = {"pos": np.zeros((T_STEPS, B, A, 2)), "vel": np.zeros((T_STEPS, B, A, 2)),
+           "obs": np.zeros((T_STEPS, B, sum(dims))), "obs_dims": np.array(dims, np.int64),
+           "rew": np.zeros((T_STEPS, B, A)), "rew_own": np.zeros((T_STEPS, B, A)), "done": np.zeros((T_STEPS, B), np.uint8),
+           "comm": np.zeros((T_STEPS, B, len(speakers) * dim_c)), "goal": aux.astype(np.int32) if n_aux > 1 else aux[:, 0].astype(np.int32),
+           "obs0": np.zeros((B, sum(dims))), "rew0": np.zeros((B, A))}
+    if info_cb is not None:
+        rec["info_c_goal"] = np.zeros((T_STEPS, B, A, 2 * dim_c))
+    env.seed(0)
+    np.random.seed(seed)
+    for b in range(B):
+        for _ in range(2000):
+            env.reset()
+            if drawn() == list(aux[b]):
+                break
+        else:
+            raise RuntimeError("landmark draws never matched")
+        inject(world, pos0[b], vel0[b])
+        rec["obs0"][b] = np.concatenate([np.asarray(sc.observation(a, world), np.float64) for a in world.agents])
+        rec["rew0"][b] = [float(sc.reward(a, world)) for a in world.agents]
+        for t in range(T_STEPS):
+            if name == "simple_reference":
+                for i, a in enumerate(world.agents):
+                    a.action.u = _move_u(int(actions[t, b, 2 * i]), a.accel)
+                    c = np.zeros(dim_c)
+                    c[int(actions[t, b, 2 * i + 1])] = 1.0          # environment.py:199-201
+                    a.action.c = c
+                world.step()
+                obs_n = [sc.observation(a, world) for a in world.agents]
+                own = [sc.reward(a, world) for a in world.agents]
+                rew_n = [np.sum(own)] * A                            # environment.py:103-105
+                done, inf_n = False, None
+            else:
+                obs_n, rew_n, done, info_n = env.step([int(x) for x in actions[t, b]])
+                own = [info_n["r%d" % i] for i in range(A)]
+                inf_n = info_n["n"]
+            for i, ag in enumerate(world.agents):
+                rec["pos"][t, b, i] = ag.state.p_pos
+                rec["vel"][t, b, i] = ag.state.p_vel
+            rec["obs"][t, b] = np.concatenate([np.asarray(o, np.float64) for o in obs_n])
+            rec["rew"][t, b] = [float(r) for r in rew_n]
+            rec["rew_own"][t, b] = [float(r) for r in own]
+            rec["done"][t, b] = bool(done)
+            rec["comm"][t, b] = np.concatenate([world.agents[i].state.c for i in speakers])
+            if info_cb is not None:
+                rec["info_c_goal"][t, b] = [np.concatenate([np.asarray(x[0], np.float64), np.asarray(x[1], np.float64)]) for x in inf_n]
+    return pos0, vel0, actions, rec
+
+
 def known_answers(ref):
     """Anchors that do not use state injection."""
     out = {}
@@ -568,6 +669,10 @@ def main():
         pos0, vel0, actions, rec = run_classic(ref, name, seed)
         cases[name] = (name, {}, pos0, vel0, actions, rec)
 
+    for name, seed in (("simple_speaker_listener", 20240621), ("simple_reference", 20240622), ("simple_crypto", 20240623)):
+        pos0, vel0, actions, rec = run_comm(ref, name, seed)
+        cases[name] = (name, {}, pos0, vel0, actions, rec)
+
     for key, (scn, kw, pos0, vel0, actions, rec) in cases.items():
         path = os.path.join(OUT, key + ".npz")
         np.savez_compressed(path, scenario=np.array(scn), pos0=pos0, vel0=vel0,
@@ -598,6 +703,11 @@ def main():
                     dev["obs"] = np.abs(np.concatenate(obs, axis=1) - rec["obs"][t]).max()
                 if "info_sq" in rec:
                     dev["info_sq"] = np.abs(orc.info(spec, pos, rec["goal"])["sq"] - rec["info_sq"][t]).max()
+                if "rew_own" in rec:
+                    dev["rew_own"] = np.abs(orc.reward(spec, pos, rec["goal"], comm) - rec["rew_own"][t]).max()
+                    dev["comm"] = np.abs(comm[:, ~spec.silent].reshape(comm.shape[0], -1) - rec["comm"][t]).max()
+                if "info_c_goal" in rec:
+                    dev["info_c_goal"] = np.abs(orc.info(spec, pos, rec["goal"], comm)["c_goal"] - rec["info_c_goal"][t]).max()
                 for k, v in dev.items():
                     worst[k] = max(worst.get(k, 0.0), float(v))
             print(key, "oracle-vs-reference max |delta|:", worst)
