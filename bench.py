@@ -127,8 +127,9 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
     actions = torch.randint(0, 5, (EPISODE, B, n_act), generator=gen, device=dev, dtype=torch.int32)
-    if args.scenario == "simple_world_comm":
-        actions[:, :, 1] = torch.randint(0, 4, (EPISODE, B), generator=gen, device=dev, dtype=torch.int32)
+    for col, n in enumerate(env.action_dims):        # comm words are uniform over dim_c
+        if n != 5:
+            actions[:, :, col] = torch.randint(0, n, (EPISODE, B), generator=gen, device=dev, dtype=torch.int32)
     out = None
     pairs = []                                  # (start, end, steps) events around dominant-kernel launches
     graphs = {}

@@ -57,6 +57,10 @@ class BatchedEnv:
         self.layout = lo
         A, L, B = lo.n_agents, lo.n_landmarks, self.n_envs
         self.n_agents, self.n_landmarks, self.n_act = A, L, lo.n_act
+        # number of choices of every action column, in the reference's action_n order
+        self.action_dims = []
+        for i in range(A):
+            self.action_dims += ([5] if self.spec.movable[i] else []) + ([lo.dim_c] if not self.spec.silent[i] else [])
         self.obs_dims = [lo.obs_dim[i] for i in range(A)]
         self.obs_offsets = [lo.obs_offset[i] for i in range(A)]
         z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)

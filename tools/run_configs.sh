@@ -17,3 +17,9 @@ run tag_B131072 --scenario simple_tag --envs 131072 --steps 1000 --warmup 100
 run wcomm_B262144 --scenario simple_world_comm --envs 262144 --steps 500 --warmup 50
 run spread64_B2048 --agents 64 --landmarks 64 --envs 2048 --steps 500 --warmup 50
 run spread64_f64_B2048 --agents 64 --landmarks 64 --envs 2048 --dtype f64 --steps 100 --warmup 25
+run simple_B262144 --scenario simple --envs 262144 --steps 1000 --warmup 100
+run adversary_B262144 --scenario simple_adversary --envs 262144 --steps 1000 --warmup 100
+run push_B262144 --scenario simple_push --envs 262144 --steps 1000 --warmup 100
+run speaker_listener_B262144 --scenario simple_speaker_listener --envs 262144 --steps 1000 --warmup 100
+run reference_B262144 --scenario simple_reference --envs 262144 --steps 1000 --warmup 100
+run crypto_B262144 --scenario simple_crypto --envs 262144 --steps 1000 --warmup 100
