@@ -75,6 +75,12 @@ extern "C" {
 #define MPE_SCN_REFERENCE 8  /* multiagent/scenarios/simple_reference.py */
 #define MPE_SCN_CRYPTO 9     /* multiagent/scenarios/simple_crypto.py */
 
+/* World.step variants (MpeSpec.physics) */
+#define MPE_PHYSICS_CORE 0     /* multiagent/core.py:142-233 */
+#define MPE_PHYSICS_NEW_CORE 1 /* multiagent/new_core.py:188-298: action force scaled by mass (* accel) (:214),
+                                  contact between two movable entities split by their mass ratio (:290-294);
+                                  mpe_world_step only (MPE_SCN_NONE) */
+
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_LANDMARKS 64
 #define MPE_MAX_WALLS 16
@@ -115,6 +121,10 @@ typedef struct MpeSpec {
     const double* wall_width;      /* [W] Wall.width */
     const uint8_t* wall_hard;      /* [W] Wall.hard */
     const uint8_t* ghost;          /* [A] Agent.ghost: passes through walls that are not hard (NULL = none) */
+    int32_t physics;               /* MPE_PHYSICS_* */
+    int32_t reserved;
+    const double* accel;           /* [A] Agent.accel, NaN when None; read when physics == MPE_PHYSICS_NEW_CORE
+                                      (the action force is (mass * accel, or mass when None) * u, new_core.py:214) */
 } MpeSpec;
 
 /* Derived sizes of the caller-allocated buffers. */
@@ -231,6 +241,8 @@ int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask
  * comm actions c T[B][S*dim_c] (agent.action.c of the speakers, may be NULL if S == 0) are given
  * directly; pos, vel, comm are updated in place.  Wall contact (get_wall_collision_force,
  * core.py:270-307) is applied to every agent after its entity contacts, as in core.py:182-188.
+ * Immovable agents keep their state (core.py:195).  With MPE_PHYSICS_NEW_CORE the step is
+ * new_core.py:188-298 (its distance cache, :147-170, only stores what the step computes anyway).
  */
 int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* vel, void* comm,
                    mpe_stream_t stream);

@@ -186,6 +186,10 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     memset(h, 0, sizeof(*h));
     HostSpec& s = h->spec;
     s.scenario = spec->scenario; s.A = A; s.L = L; s.dim_c = spec->dim_c; s.collaborative = spec->collaborative ? 1 : 0;
+    s.physics = spec->physics;
+    if (s.physics != MPE_PHYSICS_CORE && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: unknown physics %d", s.physics); }
+    if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step only (MPE_SCN_NONE)"); }
+    if (s.physics == MPE_PHYSICS_NEW_CORE && !spec->accel) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: new_core physics needs the accel array"); }
     s.dt = spec->dt; s.damping = spec->damping; s.contact_force = spec->contact_force; s.contact_margin = spec->contact_margin;
     for (int e = 0; e < A + L; ++e) {
         s.size[e] = spec->size[e]; s.mass[e] = spec->mass[e];
@@ -199,6 +203,8 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
         s.leader[i] = (spec->leader && spec->leader[i]) ? 1 : 0;
         s.ghost[i] = (spec->ghost && spec->ghost[i]) ? 1 : 0;
         if (isnan(s.max_speed[i])) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: max_speed[%d] is NaN (use +inf for no limit)", i); }
+        s.force_scale[i] = 1.0;
+        if (s.physics == MPE_PHYSICS_NEW_CORE) s.force_scale[i] = isnan(spec->accel[i]) ? s.mass[i] : s.mass[i] * spec->accel[i];
     }
     s.n_walls = spec->n_walls;
     if (s.n_walls < 0 || s.n_walls > MPE_MAX_WALLS) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: 0..%d walls (got %d)", MPE_MAX_WALLS, spec->n_walls); }
@@ -236,8 +242,9 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
         DevTable t;
         memset(&t, 0, sizeof(t));
         for (int k = 0; k < A + L; ++k) { t.size[k] = s.size[k]; t.mass[k] = s.mass[k]; t.collide[k] = s.collide[k]; t.movable[k] = s.movable[k]; }
-        for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; t.ghost[i] = s.ghost[i]; }
+        for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; t.ghost[i] = s.ghost[i]; t.force_scale[i] = s.force_scale[i]; }
         t.n_walls = s.n_walls;
+        t.new_core = s.physics == MPE_PHYSICS_NEW_CORE ? 1 : 0;
         for (int w = 0; w < s.n_walls; ++w) {
             t.wall_vertical[w] = s.wall_vertical[w]; t.wall_hard[w] = s.wall_hard[w]; t.wall_axis_pos[w] = s.wall_axis_pos[w];
             t.wall_end0[w] = s.wall_end0[w]; t.wall_end1[w] = s.wall_end1[w]; t.wall_width[w] = s.wall_width[w];

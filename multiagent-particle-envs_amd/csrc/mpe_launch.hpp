@@ -12,12 +12,13 @@ constexpr int MAX_E = MPE_MAX_AGENTS + MPE_MAX_LANDMARKS;
 
 // Validated copy of MpeSpec (host memory).
 struct HostSpec {
-    int scenario, A, L, dim_c, collaborative;
+    int scenario, A, L, dim_c, collaborative, physics;
     double dt, damping, contact_force, contact_margin;
     double size[MAX_E], mass[MAX_E];
     uint8_t movable[MAX_E], collide[MAX_E];
     double sens[MPE_MAX_AGENTS], max_speed[MPE_MAX_AGENTS];
     uint8_t silent[MPE_MAX_AGENTS], adversary[MPE_MAX_AGENTS], leader[MPE_MAX_AGENTS], ghost[MPE_MAX_AGENTS];
+    double force_scale[MPE_MAX_AGENTS];     // action force = force_scale * u: 1 (core.py:166) or mass (* accel) (new_core.py:214)
     int n_walls;
     uint8_t wall_vertical[MPE_MAX_WALLS], wall_hard[MPE_MAX_WALLS];
     double wall_axis_pos[MPE_MAX_WALLS], wall_end0[MPE_MAX_WALLS], wall_end1[MPE_MAX_WALLS], wall_width[MPE_MAX_WALLS];
@@ -39,11 +40,12 @@ struct HostSpec {
 // Per-entity table in device memory, read by the run-time driven (wave-per-world) kernels.
 struct DevTable {
     double size[MAX_E], mass[MAX_E];
-    double sens[MPE_MAX_AGENTS], max_speed[MPE_MAX_AGENTS];
+    double sens[MPE_MAX_AGENTS], max_speed[MPE_MAX_AGENTS], force_scale[MPE_MAX_AGENTS];
     double wall_axis_pos[MPE_MAX_WALLS], wall_end0[MPE_MAX_WALLS], wall_end1[MPE_MAX_WALLS], wall_width[MPE_MAX_WALLS];
     uint8_t collide[MAX_E], movable[MAX_E], silent[MPE_MAX_AGENTS], ghost[MPE_MAX_AGENTS];
     uint8_t wall_vertical[MPE_MAX_WALLS], wall_hard[MPE_MAX_WALLS];
     int n_walls;
+    int new_core;       // contacts between movable entities are split by their mass ratio (new_core.py:290-294)
 };
 
 // On-device Scenario.reset_world fused into the start of a rollout launch (mpe_episode).

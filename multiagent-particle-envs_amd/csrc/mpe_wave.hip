@@ -93,6 +93,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     for (int k = lane; k < n_coll; k += NT) {
         const int j = coll_idx[k];
         CP[k][0] = P[j].x; CP[k][1] = P[j].y; CP[k][2] = size_s[j];
+        CP[k][3] = (tb->movable[j] != 0) ? (T)tb->mass[j] : T(0);      // mass of a movable partner, else 0
     }
     __syncthreads();
     // A partner further away than this contributes nothing: in float32 the softplus of
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     const T my_mass = (T)tb->mass[me];
     const T my_sens = (T)tb->sens[me];
     const T my_max_speed = (T)tb->max_speed[me];
+    const T my_force_scale = (T)tb->force_scale[me];
+    const bool new_core = (EPI == EPI_NONE) && tb->new_core != 0;
     const bool want_info = (info_i_g != nullptr);
     const int OD = 4 + 2 * L + 2 * (A - 1);      // simple_spread observation length
 
@@ -119,8 +122,9 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                     const int a = is_agent ? actions[row * A + lane] : 0;
                     f = decode_move<T>(a, my_sens);                       // environment.py:176-195
                 } else {
-                    f.x = is_agent ? u_g[b * (2 * A) + 2 * lane] : T(0);  // agent.action.u as given
-                    f.y = is_agent ? u_g[b * (2 * A) + 2 * lane + 1] : T(0);
+                    // agent.action.u as given; the scale is 1 (core.py:166) or mass (* accel) (new_core.py:214)
+                    f.x = my_force_scale * u_g[b * (2 * A) + 2 * lane];
+                    f.y = my_force_scale * u_g[b * (2 * A) + 2 * lane + 1];
                 }
                 // ---- contact forces: partners in ascending entity order (core.py:170-181) ----
                 // Pass 1 marks the partners within reach (squared distances only, one LDS read each);
@@ -153,7 +157,14 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                             const T* c = CP[32 * w + kk];
                             V2<T> pj;
                             pj.x = c[0]; pj.y = c[1];
-                            const V2<T> g = contact_force<T>(pi, pj, my_size + c[2], p.contact_force, p.contact_margin);
+                            V2<T> g = contact_force<T>(pi, pj, my_size + c[2], p.contact_force, p.contact_margin);
+                            if (new_core && c[3] != T(0)) {
+                                // two movable entities share the force by their masses (new_core.py:290-294): the
+                                // lower-indexed one takes m_b / m_a of it, the other 1 / (m_b / m_a)
+                                const T ratio = (32 * w + kk > my_rank) ? c[3] / my_mass : T(1) / (my_mass / c[3]);
+                                g.x = ratio * g.x;
+                                g.y = ratio * g.y;
+                            }
                             f.x = g.x + f.x;
                             f.y = g.y + f.y;
                         }

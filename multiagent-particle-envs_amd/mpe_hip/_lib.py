@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "libmpe_hip.so")
 MPE_F32, MPE_F64 = 0, 1
 SCN_NONE, SCN_SPREAD, SCN_TAG, SCN_WORLD_COMM, SCN_SIMPLE, SCN_ADVERSARY, SCN_PUSH = 0, 1, 2, 3, 4, 5, 6
 SCN_SPEAKER_LISTENER, SCN_REFERENCE, SCN_CRYPTO = 7, 8, 9
+PHYSICS_CORE, PHYSICS_NEW_CORE = 0, 1
 MAX_AGENTS = 64
 MAX_LANDMARKS = 64
 MAX_WALLS = 16
@@ -31,6 +32,7 @@ class MpeSpec(C.Structure):
         ("n_walls", C.c_int32), ("collaborative", C.c_int32),
         ("wall_vertical", _p_u8), ("wall_axis_pos", _p_f64), ("wall_end0", _p_f64), ("wall_end1", _p_f64),
         ("wall_width", _p_f64), ("wall_hard", _p_u8), ("ghost", _p_u8),
+        ("physics", C.c_int32), ("reserved", C.c_int32), ("accel", _p_f64),
     ]
 
 

@@ -36,6 +36,10 @@ class WorldSpec:
     ghost: np.ndarray = None
     # World.collaborative: step returns the summed reward to every agent (multiagent/environment.py:38,103-105)
     collaborative: bool = False
+    # World.step of multiagent/new_core.py instead of multiagent/core.py (physics-only step, SCN_NONE);
+    # accel [A] is Agent.accel with nan for None (it scales the action force, new_core.py:214)
+    new_core: bool = False
+    accel: np.ndarray = None
 
     def to_c(self):
         """Returns (MpeSpec, keepalive) -- keepalive owns the arrays the struct points into."""
@@ -52,9 +56,12 @@ class WorldSpec:
                         wall_width=f64([w["width"] for w in self.walls], W), wall_hard=u8([w["hard"] for w in self.walls], W))
         if self.ghost is not None:
             arrs["ghost"] = u8(self.ghost, A)
+        if self.new_core:
+            arrs["accel"] = f64(np.full(A, np.nan) if self.accel is None else self.accel, A)
         s = _lib.MpeSpec(scenario=self.scenario, n_agents=A, n_landmarks=self.n_landmarks, dim_c=self.dim_c,
                          dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin,
-                         n_walls=W, collaborative=int(bool(self.collaborative)))
+                         n_walls=W, collaborative=int(bool(self.collaborative)),
+                         physics=_lib.PHYSICS_NEW_CORE if self.new_core else _lib.PHYSICS_CORE)
         for k, a in arrs.items():
             ptr_t = _lib._p_f64 if a.dtype == np.float64 else _lib._p_u8
             setattr(s, k, a.ctypes.data_as(ptr_t))
@@ -157,12 +164,15 @@ def crypto_spec():
                      adversary=np.array([True, False, False]), leader=np.zeros(3, bool), name="simple_crypto")
 
 
-def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, walls=(), ghost=None, **world):
-    """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158); the
-    scenario's observation / reward callbacks stay with the caller."""
+def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, walls=(), ghost=None,
+                 movable=None, **world):
+    """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158, or with
+    ``new_core=True, accel=[...]`` multiagent/new_core.py:188-205); the scenario's observation /
+    reward callbacks stay with the caller.  ``movable`` [E] defaults to agents yes, landmarks no."""
     A, L = n_agents, n_landmarks
     return WorldSpec(_lib.SCN_NONE, A, L, dim_c, size=np.asarray(size, float), mass=np.asarray(mass, float),
-                     movable=np.r_[np.ones(A, bool), np.zeros(L, bool)], collide=np.asarray(collide, bool),
+                     movable=np.r_[np.ones(A, bool), np.zeros(L, bool)] if movable is None else np.asarray(movable, bool),
+                     collide=np.asarray(collide, bool),
                      sensitivity=np.asarray(sensitivity, float), max_speed=np.asarray(max_speed, float),
                      silent=np.asarray(silent, bool), adversary=np.zeros(A, bool), leader=np.zeros(A, bool),
                      name="physics", walls=list(walls), ghost=None if ghost is None else np.asarray(ghost, bool), **world)

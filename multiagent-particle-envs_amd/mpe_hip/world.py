@@ -50,6 +50,7 @@ class Entity:
     """Defaults of multiagent/core.py:45-71."""
 
     def __init__(self):
+        self.i = 0                 # index among all entities (multiagent/new_core.py:50)
         self.name = ""
         self.size = 0.050
         self.movable = False
@@ -104,6 +105,7 @@ class World:
         self.contact_force = 1e2
         self.contact_margin = 1e-3
         self.device = "cuda:0"
+        self.new_core = False      # World.step of multiagent/new_core.py (mpe_hip.new_core.World sets it)
         self._phys = None          # (signature, BatchedEnv) of the physics-only handle
 
     @property
@@ -121,9 +123,9 @@ class World:
     # ------------------------------------------------------------------
     def _signature(self):
         ents = self.entities
-        return (len(self.agents), len(self.landmarks), self.dim_c, self.dt, self.damping, self.contact_force, self.contact_margin,
+        return (len(self.agents), len(self.landmarks), self.dim_c, self.dt, self.damping, self.contact_force, self.contact_margin, self.new_core,
                 tuple((e.size, e.mass, bool(e.movable), bool(e.collide)) for e in ents),
-                tuple((a.max_speed, bool(a.silent), bool(getattr(a, "ghost", False))) for a in self.agents),
+                tuple((a.max_speed, bool(a.silent), bool(getattr(a, "ghost", False)), a.accel if self.new_core else None) for a in self.agents),
                 tuple((w.orient, w.axis_pos, tuple(w.endpoints), w.width, bool(w.hard)) for w in self.walls), str(self.device))
 
     def _physics_env(self):
@@ -142,8 +144,9 @@ class World:
                                 walls=[dict(orient=w.orient, axis_pos=w.axis_pos, endpoints=tuple(w.endpoints), width=w.width, hard=w.hard)
                                        for w in self.walls],
                                 ghost=[getattr(a, "ghost", False) for a in self.agents],
+                                movable=[bool(e.movable) for e in ents], new_core=self.new_core,
+                                accel=[np.nan if a.accel is None else a.accel for a in self.agents],
                                 dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin)
-            spec.movable = np.array([bool(e.movable) for e in ents])     # immovable agents keep their state; mpe_create refuses movable landmarks
             self._phys = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=self.device))
         return self._phys[1]
 
@@ -179,8 +182,11 @@ class World:
         c_rows = []
         for i, a in enumerate(self.agents):
             # motor / comm noise is drawn on the host exactly where the reference draws it
-            # (multiagent/core.py:165,211); no in-scope scenario sets it
+            # (multiagent/core.py:165,211); no in-scope scenario sets it.  new_core adds it after scaling
+            # the action (new_core.py:213-214), so it is divided by the scale the kernel applies.
             un = np.random.randn(*a.action.u.shape) * a.u_noise if a.u_noise else 0.0
+            if self.new_core and a.u_noise:
+                un = un / (a.mass * a.accel if a.accel is not None else a.mass)
             u[0, 2 * i:2 * i + 2] = np.asarray(a.action.u, dtype=np.float64) + un
             if not a.silent:
                 cn = np.random.randn(*a.action.c.shape) * a.c_noise if a.c_noise else 0.0

@@ -74,6 +74,11 @@ class Spec:
     ghost: Optional[np.ndarray] = None
     # World.collaborative: every agent receives the sum of the rewards (environment.py:103-105)
     shared: bool = False
+    # physics of multiagent/new_core.py instead of multiagent/core.py: the action force is scaled by
+    # mass (* accel) (:214) and a contact between two movable entities is split by their mass ratio
+    # (:290-294); accel [A] holds Agent.accel with nan for None
+    new_core: bool = False
+    accel: Optional[np.ndarray] = None
 
     @property
     def E(self) -> int:
@@ -326,7 +331,12 @@ def world_step(spec: Spec, pos, vel, u, c):
     force: List[Optional[np.ndarray]] = [None] * E
     for i in range(A):
         if spec.movable[i]:
-            force[i] = u[:, i, :] + 0.0
+            if spec.new_core:                           # new_core.py:214
+                acc = spec.accel[i] if spec.accel is not None else np.nan
+                scale = spec.mass[i] * acc if not np.isnan(acc) else spec.mass[i]
+                force[i] = scale * u[:, i, :] + 0.0
+            else:
+                force[i] = u[:, i, :] + 0.0
     # apply_environment_force, core.py:170-181
     for a in range(E):
         for b in range(a + 1, E):
@@ -335,14 +345,19 @@ def world_step(spec: Spec, pos, vel, u, c):
             if (not spec.movable[a]) and (not spec.movable[b]):
                 continue                                # core.py:218-219
             f = collision_force(spec, pos[:, a, :], pos[:, b, :], spec.size[a], spec.size[b])
+            fa, fb = +f, -f
+            if spec.new_core and spec.movable[a] and spec.movable[b]:
+                ratio = spec.mass[b] / spec.mass[a]     # new_core.py:290-294
+                fa = ratio * f
+                fb = -(1 / ratio) * f
             if spec.movable[a]:
                 if force[a] is None:
                     force[a] = np.zeros((B, 2))
-                force[a] = (+f) + force[a]              # core.py:178
+                force[a] = fa + force[a]                # core.py:178
             if spec.movable[b]:
                 if force[b] is None:
                     force[b] = np.zeros((B, 2))
-                force[b] = (-f) + force[b]              # core.py:181
+                force[b] = fb + force[b]                # core.py:181
     # wall contact for every movable entity, after its entity contacts (core.py:182-188)
     for i in range(A):
         if not spec.movable[i]:

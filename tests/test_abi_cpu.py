@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_mirrors_match_header_sizes():
     from mpe_hip import _lib
-    # MpeSpec: 4 int32 + 4 double + 9 pointers + 2 int32 + 7 pointers ; MpeLayout: int64 + 10 int32 + 2 * 64 int32
-    assert C.sizeof(_lib.MpeSpec) == 16 + 32 + 9 * 8 + 8 + 7 * 8
+    # MpeSpec: 4 int32 + 4 double + 9 pointers + 2 int32 + 7 pointers + 2 int32 + 1 pointer ; MpeLayout: int64 + 10 int32 + 2 * 64 int32
+    assert C.sizeof(_lib.MpeSpec) == 16 + 32 + 9 * 8 + 8 + 7 * 8 + 8 + 8
     assert C.sizeof(_lib.MpeLayout) == 8 + 10 * 4 + 2 * 64 * 4
 
 
@@ -54,7 +54,9 @@ def test_specs_match_oracle_specs():
     import mpe_oracle as orc
     from mpe_hip import make_spec
     for name, kw_p, kw_o in (("simple_spread", {}, {}), ("simple_spread", dict(n_agents=64, n_landmarks=64), dict(A=64, L=64)),
-                             ("simple_tag", {}, {}), ("simple_world_comm", {}, {})):
+                             ("simple_tag", {}, {}), ("simple_world_comm", {}, {}), ("simple", {}, {}), ("simple_adversary", {}, {}),
+                             ("simple_push", {}, {}), ("simple_speaker_listener", {}, {}), ("simple_reference", {}, {}),
+                             ("simple_crypto", {}, {})):
         p, o = make_spec(name, **kw_p), orc.make_spec(name, **kw_o)
         assert (p.n_agents, p.n_landmarks, p.dim_c) == (o.A, o.L, o.dim_c)
         for a, b in ((p.size, o.size), (p.mass, o.mass), (p.movable, o.movable), (p.collide, o.collide),

@@ -173,3 +173,29 @@ def test_reset_with_two_landmark_draws():
     spec = orc.make_spec("simple_crypto")
     pos, vel, comm, goal = orc.reset_with_goal(spec, np.random.RandomState(4), 300)
     assert goal.shape == (300, 2) and set(goal.ravel()) == {0, 1}
+
+
+def new_core_spec(g):
+    """Oracle spec of the world of tests/golden/new_core.npz (new_core.py physics, walls, one immovable agent)."""
+    A = g["accel"].shape[0]
+    L = g["size"].shape[0] - A
+    spec = orc.Spec("physics", A, L, 3, g["size"], g["movable"].astype(bool), g["collide"].astype(bool), g["mass"],
+                    sens=np.where(np.isnan(g["accel"]), 5.0, g["accel"]), max_speed=g["max_speed"], silent=np.ones(A, bool),
+                    adversary=np.zeros(A, bool), leader=np.zeros(A, bool), new_core=True, accel=g["accel"])
+    spec.walls = [dict(orient="V" if v else "H", axis_pos=float(a), endpoints=(float(e[0]), float(e[1])), width=float(w), hard=bool(h))
+                  for v, a, e, w, h in zip(g["wall_vertical"], g["wall_axis_pos"], g["wall_endpoints"], g["wall_width"], g["wall_hard"])]
+    spec.ghost = g["ghost"].astype(bool)
+    return spec
+
+
+def test_oracle_reproduces_reference_new_core_step():
+    """World.step of multiagent/new_core.py (:188-205), captured from the reference's own World.step."""
+    g = load_golden("new_core")
+    spec = new_core_spec(g)
+    A = spec.A
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    for t in range(g["actions"].shape[0]):
+        u, c = orc.decode_actions(spec, np.where(spec.movable[:A], g["actions"][t], 0)[:, spec.movable[:A]])
+        pos, vel, _ = orc.world_step(spec, pos, vel, u, c)
+        assert np.array_equal(pos[:, :A], g["pos"][t]) and np.array_equal(vel, g["vel"][t]), t
+    assert np.array_equal(g["pos"][-1][:, 6], g["pos0"][:, 6])      # the immovable agent stayed put

@@ -10,7 +10,9 @@ inputs and the numbers the reference produced.
 
 ``gym`` is not installed here, so an inert stand-in supplying only container
 classes (spaces, Env, registration, seeding) is registered before the import;
-it performs no arithmetic of the simulated path.
+it performs no arithmetic of the simulated path.  ``seaborn`` (imported by
+new_core.py for display colours only) is absent too and gets a one-function
+stand-in that returns grey tuples.
 
 Reference entry points used:
   * simple_spread, simple_tag: ``MultiAgentEnv.step`` (multiagent/environment.py:83-115)
@@ -93,6 +95,9 @@ def _install_gym_stub():
     seeding.np_random = lambda seed=None: (np.random.RandomState(seed), seed)
     utils.seeding = seeding
     gym.Space, gym.Env, gym.spaces, gym.envs, gym.utils = Space, Env, spaces, envs, utils
+    sns = types.ModuleType("seaborn")          # display colours only (new_core.py:181-182)
+    sns.color_palette = lambda *a, n_colors=None, **k: [(0.5, 0.5, 0.5)] * (n_colors or (a[1] if len(a) > 1 else 6))
+    sys.modules["seaborn"] = sns
     for name, mod in [("gym", gym), ("gym.spaces", spaces), ("gym.envs", envs),
                       ("gym.envs.registration", registration), ("gym.utils", utils),
                       ("gym.utils.seeding", seeding)]:
@@ -114,6 +119,7 @@ def load_reference():
     sys.modules["multiagent"] = pkg
     ref = types.SimpleNamespace()
     ref.core = _load("multiagent.core", os.path.join(REF, "multiagent", "core.py"))
+    ref.new_core = _load("multiagent.new_core", os.path.join(REF, "multiagent", "new_core.py"))
     _load("multiagent.scenario", os.path.join(REF, "multiagent", "scenario.py"))
     _load("multiagent.multi_discrete", os.path.join(REF, "multiagent", "multi_discrete.py"))
     ref.environment = _load("multiagent.environment", os.path.join(REF, "multiagent", "environment.py"))
@@ -390,6 +396,16 @@ def init_spread64(rng, B=2):
     return pos, vel, actions
 
 
+def _move_u(m, accel):
+    """environment.py:176-181,192-195 for one int move."""
+    u = np.zeros(2)
+    if m == 1: u[0] = -1.0
+    if m == 2: u[0] = +1.0
+    if m == 3: u[1] = -1.0
+    if m == 4: u[1] = +1.0
+    return u * (accel if accel is not None else 5.0)
+
+
 # ----------------------------------------------------------------------------
 def run_walls(ref):
     """World.step with walls (core.py:182-188, 270-307): no in-scope scenario has walls, so a
@@ -447,6 +463,87 @@ def run_walls(ref):
     return rec
 
 
+def run_new_core(ref):
+    """World.step of multiagent/new_core.py (:188-205): action force scaled by mass (* accel) (:214),
+    contacts between movable entities split by their mass ratio (:290-294), walls, speed clamp.  A
+    predator-prey-like world (heavy adversaries, light good agents, one immovable agent, an obstacle,
+    walls) is assembled from the reference classes; it is stepped with and without the distance cache
+    (cache_dists), which must not change a bit."""
+    nc = ref.new_core
+    rng = np.random.RandomState(20240631)
+    B, A, L = 24, 7, 3
+    walls = [dict(orient="H", axis_pos=-1.2, endpoints=(-1.2, 1.2), width=0.4, hard=True),
+             dict(orient="V", axis_pos=-1.2, endpoints=(-1.2, 1.2), width=0.4, hard=True),
+             dict(orient="H", axis_pos=1.2, endpoints=(-1.2, 1.2), width=0.4, hard=True),
+             dict(orient="V", axis_pos=1.2, endpoints=(-1.2, 1.2), width=0.4, hard=False)]
+
+    def build(cache):
+        world = nc.World()
+        world.dim_c = 3
+        world.cache_dists = cache
+        world.agents = [nc.Agent() for _ in range(A)]
+        for i, a in enumerate(world.agents):
+            a.i = i
+            a.collide, a.silent = True, True
+            adv = i < 3
+            a.size, a.initial_mass, a.max_speed = (0.065, 2.25, 1.0) if adv else (0.045, 1.0, 1.3)
+            a.accel = 1.5 if i in (1, 5) else None
+            a.ghost = (i == 4)
+            a.action.c = np.zeros(3)
+        world.agents[6].movable = False
+        world.landmarks = [nc.Landmark() for _ in range(L)]
+        for l, lm in enumerate(world.landmarks):
+            lm.i = A + l
+            lm.collide, lm.movable, lm.size = (l == 0), False, (0.2 if l == 0 else 0.03)
+        world.walls = [nc.Wall(orient=w["orient"], axis_pos=w["axis_pos"], endpoints=w["endpoints"], width=w["width"], hard=w["hard"])
+                       for w in walls]
+        return world
+
+    pos0 = np.concatenate([rng.uniform(-1, 1, (B, A, 2)), rng.uniform(-0.9, 0.9, (B, L, 2))], axis=1)
+    vel0 = rng.uniform(-0.5, 0.5, (B, A, 2))
+    vel0[:, 6] = 0.0
+    # heavy-light, heavy-heavy, light-light pairs and an agent-obstacle pair in contact; agents at the walls
+    for b in range(12):
+        i, j = [(0, 3), (0, 1), (3, 5), (1, 4), (2, 6), (5, 6)][b % 6]
+        d = [0.02, 0.06, 0.1, 0.105, 0.115, 0.09][b // 2]
+        ang = rng.uniform(0, 2 * np.pi)
+        pos0[b, j] = pos0[b, i] + d * np.array([np.cos(ang), np.sin(ang)])
+    for b in range(12, 16):
+        pos0[b, b % 6] = pos0[b, A] + 0.22 * np.array([np.cos(b), np.sin(b)])
+    for b in range(16, 24):
+        k = b - 16
+        pos0[b, k % 6] = [(-0.99, 0.3), (0.3, -1.01), (0.98, 0.2), (-0.2, 1.0), (1.05, 1.05), (-1.0, -1.0), (0.0, 0.97), (0.99, 0.99)][k]
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+    recs = []
+    for cache in (False, True):
+        world = build(cache)
+        rec = {"pos": np.zeros((T_STEPS, B, A, 2)), "vel": np.zeros((T_STEPS, B, A, 2))}
+        for b in range(B):
+            inject(world, pos0[b], vel0[b])
+            if cache:
+                world.cached_dist_vect = None
+                world.calculate_distances()
+            for t in range(T_STEPS):
+                for i, a in enumerate(world.agents):
+                    a.action.u = _move_u(int(actions[t, b, i]), a.accel)      # what _set_action leaves in action.u
+                world.step()
+                rec["pos"][t, b] = [a.state.p_pos for a in world.agents]
+                rec["vel"][t, b] = [a.state.p_vel for a in world.agents]
+        recs.append(rec)
+    assert np.array_equal(recs[0]["pos"], recs[1]["pos"]) and np.array_equal(recs[0]["vel"], recs[1]["vel"]), "cache_dists changed the step"
+    rec = recs[0]
+    world = build(False)
+    rec.update(pos0=pos0, vel0=vel0, actions=actions.astype(np.int32),
+               size=np.array([e.size for e in world.entities]), mass=np.array([e.mass for e in world.entities]),
+               movable=np.array([e.movable for e in world.entities]), collide=np.array([e.collide for e in world.entities]),
+               accel=np.array([np.nan if a.accel is None else a.accel for a in world.agents]),
+               max_speed=np.array([a.max_speed for a in world.agents]), ghost=np.array([a.ghost for a in world.agents]),
+               wall_vertical=np.array([w["orient"] == "V" for w in walls]), wall_axis_pos=np.array([w["axis_pos"] for w in walls]),
+               wall_endpoints=np.array([w["endpoints"] for w in walls]), wall_width=np.array([w["width"] for w in walls]),
+               wall_hard=np.array([w["hard"] for w in walls]))
+    return rec
+
+
 def run_classic(ref, name, seed, B=32):
     """simple / simple_adversary / simple_push through MultiAgentEnv.step.  The goal landmark is the
     reference's own np.random.choice draw (reset is repeated until it yields the wanted index, so the
@@ -497,16 +594,6 @@ def run_classic(ref, name, seed, B=32):
             if info_cb is not None:
                 rec["info_sq"][t, b] = np.concatenate([np.atleast_1d(np.asarray(x, np.float64)) for x in info_n["n"]])
     return pos0, vel0, actions, rec
-
-
-def _move_u(m, accel):
-    """environment.py:176-181,192-195 for one int move."""
-    u = np.zeros(2)
-    if m == 1: u[0] = -1.0
-    if m == 2: u[0] = +1.0
-    if m == 3: u[1] = -1.0
-    if m == 4: u[1] = +1.0
-    return u * (accel if accel is not None else 5.0)
 
 
 def run_comm(ref, name, seed, B=32):
@@ -681,6 +768,8 @@ def main():
     walls = run_walls(ref)
     np.savez_compressed(os.path.join(OUT, "walls.npz"), **walls)
     print("wrote walls.npz")
+    np.savez_compressed(os.path.join(OUT, "new_core.npz"), **run_new_core(ref))
+    print("wrote new_core.npz")
     kat = known_answers(ref)
     np.savez_compressed(os.path.join(OUT, "kat.npz"), **kat)
     print("wrote kat.npz")
