@@ -65,6 +65,14 @@ static const char* check_structure(const HostSpec& s) {
     switch (s.scenario) {
         case MPE_SCN_NONE:
             return nullptr;
+        case MPE_SCN_PREDATOR_PREY:
+            if (A != 7 || L != 6 || s.n_walls != 4) return "simple_predator_prey has 7 agents, 6 landmarks and 4 walls";
+            for (int i = 0; i < A; ++i)
+                if (!s.collide[i] || !s.silent[i] || s.adversary[i] != (i < 3) || s.leader[i] != (i == 0 || i == 3))
+                    return "simple_predator_prey: 3 adversaries then 4 good agents, agents 0 and 3 lead, all collide and are silent";
+            for (int l = 0; l < L; ++l)
+                if (s.collide[A + l] != (l == 0)) return "simple_predator_prey: only the barrier (first landmark) collides";
+            return nullptr;
         case MPE_SCN_REFERENCE:
             if (A != 2 || L != 3 || s.dim_c != 10) return "simple_reference has 2 agents, 3 landmarks, dim_c 10";
             for (int i = 0; i < A; ++i)
@@ -145,6 +153,7 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
             case MPE_SCN_SPEAKER_LISTENER: d = (i == 0) ? 3 : 2 + 2 * L + s.dim_c; break;
             case MPE_SCN_REFERENCE: d = 2 + 2 * L + 3 + s.dim_c; break;
             case MPE_SCN_CRYPTO: d = (i == 0) ? s.dim_c : 2 * s.dim_c; break;
+            case MPE_SCN_PREDATOR_PREY: d = 4 + 4 * (A - 1) + 3 + 2 * L + 2; break;
             default: d = 0;
         }
         lo->obs_dim[i] = d;
@@ -160,6 +169,7 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
         case MPE_SCN_SPEAKER_LISTENER: lo->n_info_i = 1; lo->n_info_f = A; break;
         case MPE_SCN_REFERENCE: lo->n_info_i = 2; lo->n_info_f = A; break;
         case MPE_SCN_CRYPTO: lo->n_info_i = 2; lo->n_info_f = A * 2 * s.dim_c; break;
+        case MPE_SCN_PREDATOR_PREY: lo->n_info_i = A + 1; break;
         default: break;
     }
     lo->n_aux = s.n_aux();
@@ -188,7 +198,11 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     s.scenario = spec->scenario; s.A = A; s.L = L; s.dim_c = spec->dim_c; s.collaborative = spec->collaborative ? 1 : 0;
     s.physics = spec->physics;
     if (s.physics != MPE_PHYSICS_CORE && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: unknown physics %d", s.physics); }
-    if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step only (MPE_SCN_NONE)"); }
+    if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE && spec->scenario != MPE_SCN_PREDATOR_PREY) {
+        delete h;
+        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step (MPE_SCN_NONE) and simple_predator_prey only");
+    }
+    if (spec->scenario == MPE_SCN_PREDATOR_PREY && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: simple_predator_prey runs on the new_core physics"); }
     if (s.physics == MPE_PHYSICS_NEW_CORE && !spec->accel) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: new_core physics needs the accel array"); }
     s.dt = spec->dt; s.damping = spec->damping; s.contact_force = spec->contact_force; s.contact_margin = spec->contact_margin;
     for (int e = 0; e < A + L; ++e) {
@@ -209,7 +223,7 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     s.n_walls = spec->n_walls;
     if (s.n_walls < 0 || s.n_walls > MPE_MAX_WALLS) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: 0..%d walls (got %d)", MPE_MAX_WALLS, spec->n_walls); }
     if (s.n_walls > 0) {
-        if (spec->scenario != MPE_SCN_NONE) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: walls are simulated by mpe_world_step only (MPE_SCN_NONE)"); }
+        if (spec->scenario != MPE_SCN_NONE && spec->scenario != MPE_SCN_PREDATOR_PREY) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: walls are simulated by mpe_world_step (MPE_SCN_NONE) and simple_predator_prey only"); }
         if (!spec->wall_vertical || !spec->wall_axis_pos || !spec->wall_end0 || !spec->wall_end1 || !spec->wall_width || !spec->wall_hard) {
             delete h;
             return fail(nullptr, MPE_ERR_INVALID, "mpe_create: a wall array is NULL");

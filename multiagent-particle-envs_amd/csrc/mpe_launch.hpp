@@ -28,6 +28,7 @@ struct HostSpec {
         switch (scenario) {
             case MPE_SCN_ADVERSARY: case MPE_SCN_PUSH: case MPE_SCN_SPEAKER_LISTENER: return 1;
             case MPE_SCN_REFERENCE: case MPE_SCN_CRYPTO: return 2;
+            case MPE_SCN_PREDATOR_PREY: return 3;
             default: return 0;
         }
     }
@@ -80,7 +81,9 @@ struct StepArgs {
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112
 // from U(-0.9,0.9).
-inline double landmark_limit(const HostSpec& s) { return (s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM) ? 0.9 : 1.0; }
+inline double landmark_limit(const HostSpec& s) {
+    return (s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM || s.scenario == MPE_SCN_PREDATOR_PREY) ? 0.9 : 1.0;
+}
 
 // small in-register scenarios (mpe_small.hip); mode: 0 step, 1 rollout, 2 observe
 bool small_supported(const HostSpec& s);

@@ -221,11 +221,12 @@ struct Philox {
 // Position of entity `e` of world `b` in episode rs.episode: the two coordinates come from the
 // Philox block with key = seed and counter = (b, episode * 256 + e), mapped like numpy's
 // uniform(low, high) = low + (high - low) * random_sample().  Shared by reset_kernel and the
-// fused reset of the rollout kernels so both produce the same worlds.
+// fused reset of the rollout kernels so both produce the same worlds.  `attempt` > 0 gives the
+// redraws of a placement that is repeated until it is free (bits 48.. of the counter's high word).
 template <class RS>
-__host__ __device__ inline V2<double> reset_draw(const RS& rs, unsigned long long b, int e, bool is_agent) {
+__host__ __device__ inline V2<double> reset_draw(const RS& rs, unsigned long long b, int e, bool is_agent, int attempt = 0) {
     uint32_t r[4];
-    Philox::block(rs.seed, b, rs.episode * 256ull + (unsigned long long)e, r);
+    Philox::block(rs.seed, b, rs.episode * 256ull + (unsigned long long)e + ((unsigned long long)attempt << 48), r);
     const double lim = is_agent ? 1.0 : rs.landmark_lim;
     V2<double> d;
     d.x = -lim + (lim + lim) * Philox::u01(r[0], r[1]);
@@ -243,6 +244,25 @@ __host__ __device__ inline int reset_aux(const RS& rs, unsigned long long b, int
     uint32_t r[4];
     Philox::block(rs.seed, b, rs.episode * 256ull + 255ull, r);
     return (int)(((uint64_t)r[k] * (uint64_t)n_landmarks) >> 32);
+}
+
+// Random 32-bit word of world `b` in episode rs.episode (word 0 of the block the landmark indices
+// come from): seeds the per-world respawn stream of scenarios whose post_step draws positions.
+template <class RS>
+__host__ __device__ inline int reset_stream_key(const RS& rs, unsigned long long b) {
+    uint32_t r[4];
+    Philox::block(rs.seed, b, rs.episode * 256ull + 255ull, r);
+    return (int)r[0];
+}
+
+// n-th respawn position of world `b`, U(-lim, lim)^2, from the world's own stream key.
+__host__ __device__ inline V2<double> respawn_draw(int key, unsigned long long b, int n, double lim) {
+    uint32_t r[4];
+    Philox::block(0x5eed5eed00000000ull | (uint32_t)key, b, (unsigned long long)(uint32_t)n, r);
+    V2<double> d;
+    d.x = -lim + (lim + lim) * Philox::u01(r[0], r[1]);
+    d.y = -lim + (lim + lim) * Philox::u01(r[2], r[3]);
+    return d;
 }
 
 }  // namespace mpe

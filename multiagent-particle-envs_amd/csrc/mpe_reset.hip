@@ -4,12 +4,15 @@
 // Philox-4x32-10 block with key = seed and counter = (b, n * 256 + e), so a reset is reproducible
 // and independent of batch size, launch geometry and of which other worlds are reset with it.
 #include "mpe_launch.hpp"
-#include "mpe_math.hpp"
+#include "mpe_scenarios.hpp"
 
 namespace mpe {
 
+struct ResetSizes { double size_d[16]; };      // float64 Entity.size of scenarios whose reset tests placements
+
 template <typename T>
-__global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, int comm_rows, int n_aux, bool env_major, const ResetArgs rs,
+__global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, int comm_rows, int n_aux, bool env_major, int scenario,
+                                                    const ResetSizes sizes, const ResetArgs rs,
                                                     const uint8_t* __restrict__ mask, T* __restrict__ pos,
                                                     T* __restrict__ vel, T* __restrict__ comm, int32_t* __restrict__ aux) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -17,24 +20,39 @@ __global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, i
     if (mask != nullptr && mask[b] == 0) return;
     // element (row r of n_rows, env b): env-minor r*B + b, env-major b*n_rows + r
     auto at = [=](int r, int n_rows) -> long long { return env_major ? b * n_rows + r : (long long)r * B + b; };
-    for (int e = 0; e < E; ++e) {
-        const V2<double> d = reset_draw(rs, (unsigned long long)b, e, e < A);
-        pos[at(2 * e, 2 * E)] = (T)d.x;
-        pos[at(2 * e + 1, 2 * E)] = (T)d.y;
+    if (scenario == MPE_SCN_PREDATOR_PREY) {
+        // foods are redrawn until they are clear of the barrier and the forests; flags and respawn stream start fresh
+        typedef PredatorPreyCfg C;
+        V2<double> d[C::E];
+        for (int e = 0; e < C::E; ++e) d[e] = reset_draw(rs, (unsigned long long)b, e, e < A);
+        C::fix_reset(rs, (unsigned long long)b, d, sizes);
+        for (int e = 0; e < C::E; ++e) {
+            pos[at(2 * e, 2 * E)] = (T)d[e].x;
+            pos[at(2 * e + 1, 2 * E)] = (T)d[e].y;
+        }
+        for (int k = 0; k < n_aux; ++k) aux[at(k, n_aux)] = C::initial_aux(rs, (unsigned long long)b, k);
+    } else {
+        for (int e = 0; e < E; ++e) {
+            const V2<double> d = reset_draw(rs, (unsigned long long)b, e, e < A);
+            pos[at(2 * e, 2 * E)] = (T)d.x;
+            pos[at(2 * e + 1, 2 * E)] = (T)d.y;
+        }
+        for (int k = 0; k < n_aux; ++k) aux[at(k, n_aux)] = reset_aux(rs, (unsigned long long)b, k, E - A);
     }
     for (int r = 0; r < 2 * A; ++r) vel[at(r, 2 * A)] = T(0);
     for (int r = 0; r < comm_rows; ++r) comm[at(r, comm_rows)] = T(0);
-    for (int k = 0; k < n_aux; ++k) aux[at(k, n_aux)] = reset_aux(rs, (unsigned long long)b, k, E - A);
 }
 
 hipError_t launch_reset(const HostSpec& s, long long B, int dtype, int comm_rows, bool env_major, unsigned long long seed,
                         unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, int32_t* aux, hipStream_t st) {
     const ResetArgs rs{1, seed, episode, landmark_limit(s)};
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    ResetSizes sizes = {};
+    for (int e = 0; e < s.E() && e < 16; ++e) sizes.size_d[e] = s.size[e];
     if (dtype == MPE_F64)
-        hipLaunchKernelGGL(reset_kernel<double>, grid, block, 0, st, B, s.E(), s.A, comm_rows, s.n_aux(), env_major, rs, mask, (double*)pos, (double*)vel, (double*)comm, aux);
+        hipLaunchKernelGGL(reset_kernel<double>, grid, block, 0, st, B, s.E(), s.A, comm_rows, s.n_aux(), env_major, s.scenario, sizes, rs, mask, (double*)pos, (double*)vel, (double*)comm, aux);
     else
-        hipLaunchKernelGGL(reset_kernel<float>, grid, block, 0, st, B, s.E(), s.A, comm_rows, s.n_aux(), env_major, rs, mask, (float*)pos, (float*)vel, (float*)comm, aux);
+        hipLaunchKernelGGL(reset_kernel<float>, grid, block, 0, st, B, s.E(), s.A, comm_rows, s.n_aux(), env_major, s.scenario, sizes, rs, mask, (float*)pos, (float*)vel, (float*)comm, aux);
     return hipGetLastError();
 }
 

@@ -10,6 +10,8 @@
 
 namespace mpe {
 
+constexpr int SMALL_MAX_WALLS = 4;
+
 template <typename T, int E, int A>
 struct SmallParams {
     T size[E];
@@ -18,15 +20,29 @@ struct SmallParams {
     T max_speed[A];
     T dt, one_minus_damping, contact_force, contact_margin;
     long long n_envs;
+    // read by scenarios on the new_core physics with walls only
+    T force_scale[A];                           // mass (* accel): new_core.py:214
+    T wall_axis_pos[SMALL_MAX_WALLS], wall_end0[SMALL_MAX_WALLS], wall_end1[SMALL_MAX_WALLS], wall_width[SMALL_MAX_WALLS];
+    unsigned char wall_vertical[SMALL_MAX_WALLS], wall_hard[SMALL_MAX_WALLS], ghost[A];
+    double size_d[E];                           // float64 sizes for the reset's placement test
 };
 
 // Defaults of a scenario description; a scenario overrides what differs.
 struct CfgBase {
     static constexpr int BITS = 3;          // bits kept of every action int (moves 0..4, comm words 0..dim_c-1)
     static constexpr bool SHARED = false;   // World.collaborative: step returns the summed reward to every agent
-    static constexpr int N_AUX = 0;         // landmark indices reset_world draws and keeps for the episode
+    static constexpr int N_AUX = 0;         // int32 rows of scenario state: landmark indices reset_world draws ...
+    static constexpr bool DYNAMIC = false;  // ... or state post_step rewrites every step (then landmarks may move too)
+    static constexpr bool NEW_CORE = false; // World.step of multiagent/new_core.py (mass-scaled action, mass-ratio contacts)
+    static constexpr int N_WALLS = 0;
     __host__ __device__ static constexpr bool movable(int) { return true; }    // Agent.movable
     __host__ __device__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
+    // envs per wave: fewer when a 64-row observation tile does not fit the LDS
+    template <typename T> __host__ __device__ static constexpr int epw() { return 64; }
+    // hooks of scenarios with DYNAMIC state
+    template <class RS> __host__ __device__ static int initial_aux(const RS&, unsigned long long, int) { return 0; }
+    template <class RS, class Pos, class P> __host__ __device__ static void fix_reset(const RS&, unsigned long long, Pos&, const P&) {}
+    template <class Pos, class P> __device__ static void post_step(Pos&, int*, const P&, unsigned long long) {}
 };
 
 // simple_spread casts its observation to float32 (simple_spread.py:130); the float64 kernel keeps
@@ -622,6 +638,239 @@ struct CryptoCfg : CfgBase {
                     info_f[i * 2 * DIM_C + c] = comm[i * DIM_C + c];
                     info_f[i * 2 * DIM_C + DIM_C + c] = (c == aux[0]) ? T(1) : T(0);
                 }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// simple_predator_prey on the new_core physics: adversaries 0-2 (0 leads), good agents 3-6 (3 leads,
+// 4-6 are the members that carry food to it); landmarks [barrier, food x3, forest x2]; 4 walls
+// (multiagent/scenarios/simple_predator_prey.py).  aux[0] holds the flags post_step rewrites: bit f
+// = food f is alive, bit 3+k = member k holds food; aux[1] / aux[2] are the key and the position of
+// the world's respawn stream.  The scenario reads the distance cache World.step fills
+// (new_core.py:147-170), i.e. distances of the current positions.
+// ------------------------------------------------------------------------------------------
+struct PredatorPreyCfg : CfgBase {
+    static constexpr int N_ADV = 3, A = 7, L = 6, E = 13;
+    static constexpr int DIM_C = 0, S = 0, N_ACT = 7;             // world.dim_c = 3 but every agent is silent
+    static constexpr int BARRIER = A, FOOD0 = A + 1, N_FOOD = 3, FOREST0 = A + 4;
+    static constexpr int GOOD_LEADER = 3, MEMBER0 = 4, N_MEMBERS = 3;
+    static constexpr int OBS_DIM = 4 + 4 * (A - 1) + N_MEMBERS + 2 * L + 2;      // 45 for every role
+    static constexpr int OBS_TOTAL = A * OBS_DIM;
+    static constexpr int NI = A + 1, NF = 0, N_AUX = 3;           // info: collisions per agent, the flags
+    static constexpr bool DYNAMIC = true, NEW_CORE = true;
+    static constexpr int N_WALLS = 4;
+    __host__ __device__ static constexpr bool collides(int e) { return e <= A; }      // agents and the barrier (:34,47,56,65)
+    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
+    __host__ __device__ static constexpr bool leader(int i) { return i == 0 || i == GOOD_LEADER; }
+    __host__ __device__ static constexpr bool member(int i) { return i >= MEMBER0; }
+    // a float64 tile of 64 x 315 observations is larger than the LDS
+    template <typename T> __host__ __device__ static constexpr int epw() { return sizeof(T) == 8 ? 32 : 64; }
+
+    __device__ static __forceinline__ bool holds(int flags, int i) { return (flags >> (3 + i - MEMBER0)) & 1; }
+
+    template <typename T, class P>
+    __device__ static __forceinline__ void forest_bits(const V2<T> (&pos)[E], const P& p, bool (&inf)[A][2]) {
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                inf[i][f] = touching<T>(pos[i], pos[FOREST0 + f], p.size[i] + p.size[FOREST0 + f]);
+    }
+
+    // visibility test of simple_predator_prey.py:325
+    __device__ static __forceinline__ bool sees(int i, bool i1, bool i2, bool o1, bool o2) {
+        return (i1 && o1) || (i2 && o2) || (!i1 && !o1 && !i2 && !o2) || leader(i);
+    }
+
+    // observation() :300-349; offsets are cached_dist_vect[agent, other] = p_agent - p_other; cast to float32
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, const P& p, T* row) {
+        bool inf[A][2];
+        forest_bits<T>(pos, p, inf);
+        const int flags = aux[0];
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            row[k++] = round_f32(vel[i].x); row[k++] = round_f32(vel[i].y);
+            row[k++] = round_f32(pos[i].x); row[k++] = round_f32(pos[i].y);
+            if (member(i)) row[k++] = holds(flags, i) ? T(1) : T(-1);
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i) continue;
+                const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
+                row[k++] = vis ? round_f32(pos[i].x - pos[j].x) : T(0);
+                row[k++] = vis ? round_f32(pos[i].y - pos[j].y) : T(0);
+            }
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == i) continue;
+                const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
+                row[k++] = vis ? round_f32(vel[j].x) : T(0);
+                row[k++] = vis ? round_f32(vel[j].y) : T(0);
+            }
+#pragma unroll
+            for (int j = MEMBER0; j < A; ++j) {
+                if (j == i) continue;
+                const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
+                row[k++] = vis ? (holds(flags, j) ? T(1) : T(-1)) : T(0);
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) { row[k++] = round_f32(pos[i].x - pos[A + l].x); row[k++] = round_f32(pos[i].y - pos[A + l].y); }
+            row[k++] = inf[i][0] ? T(1) : T(-1);
+            row[k++] = inf[i][1] ? T(1) : T(-1);
+        }
+    }
+
+    // reward() :171-275 and benchmark_data() :148-156
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int* aux, const P& p, T* rew, bool want_info, int* info_i, T*) {
+        const int flags = aux[0];
+        bool hit[A][N_ADV];     // hit[g][a]: good agent g touches adversary a
+        T dist[A][N_ADV];
+#pragma unroll
+        for (int g = N_ADV; g < A; ++g)
+#pragma unroll
+            for (int a = 0; a < N_ADV; ++a) {
+                dist[g][a] = norm2<T>(pos[a].x - pos[g].x, pos[a].y - pos[g].y);
+                hit[g][a] = dist[g][a] < p.size[a] + p.size[g];
+            }
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            T r;
+            if (adversary(i)) {                     // :243-275
+                T dmin = dist[N_ADV][i];
+                T n = T(0);
+#pragma unroll
+                for (int g = N_ADV; g < A; ++g) {
+                    if (g > N_ADV) dmin = py_min<T>(dmin, dist[g][i]);
+                    n = n + (hit[g][i] ? T(1) : T(0));
+                }
+                r = T(0) - T(0.1) * dmin;
+                r = r + T(5) * n;
+                if (leader(i)) {
+#pragma unroll
+                    for (int g = MEMBER0; g < A; ++g) {     // only members ever hold food
+                        T m = T(0);
+#pragma unroll
+                        for (int a = 0; a < N_ADV; ++a) m = m + (hit[g][a] ? T(1) : T(0));
+                        if (holds(flags, g)) r = r + T(10) * m;
+                    }
+                }
+                if (want_info) {
+                    int c = 0;
+#pragma unroll
+                    for (int g = N_ADV; g < A; ++g) c += hit[g][i] ? 1 : 0;
+                    info_i[i] = c;
+                }
+            } else {                                // :183-241
+                T s = dist[i][0], n = T(0);
+#pragma unroll
+                for (int a = 0; a < N_ADV; ++a) {
+                    if (a > 0) s = s + dist[i][a];
+                    n = n + (hit[i][a] ? T(1) : T(0));
+                }
+                r = T(0.1) * s;
+                r = r - T(5) * n;
+                if (member(i)) {
+                    if (!holds(flags, i)) {
+                        T fmin = norm2<T>(pos[FOOD0].x - pos[i].x, pos[FOOD0].y - pos[i].y);
+#pragma unroll
+                        for (int f = 1; f < N_FOOD; ++f) fmin = py_min<T>(fmin, norm2<T>(pos[FOOD0 + f].x - pos[i].x, pos[FOOD0 + f].y - pos[i].y));
+                        r = r - T(0.1) * fmin;
+                    } else {
+                        r = r - T(0.1) * norm2<T>(pos[GOOD_LEADER].x - pos[i].x, pos[GOOD_LEADER].y - pos[i].y);
+                    }
+                } else {
+                    bool any = false;
+                    T dmin = T(0);
+#pragma unroll
+                    for (int m = MEMBER0; m < A; ++m) {
+                        if (!holds(flags, m)) continue;
+                        const T d = norm2<T>(pos[i].x - pos[m].x, pos[i].y - pos[m].y);
+                        dmin = any ? py_min<T>(dmin, d) : d;
+                        any = true;
+                    }
+                    if (any) r = r - T(0.1) * dmin;
+#pragma unroll
+                    for (int m = MEMBER0; m < A; ++m) {
+                        T c = T(0);
+                        if (!holds(flags, m)) {
+#pragma unroll
+                            for (int f = 0; f < N_FOOD; ++f)
+                                c = c + (touching<T>(pos[FOOD0 + f], pos[m], p.size[FOOD0 + f] + p.size[m]) ? T(1) : T(0));
+                        } else {
+                            c = touching<T>(pos[i], pos[m], p.size[i] + p.size[m]) ? T(1) : T(0);
+                        }
+                        r = r + T(5) * c;
+                    }
+                }
+                if (want_info) info_i[i] = 0;
+            }
+            rew[i] = r;
+        }
+        if (want_info) info_i[A] = flags;
+    }
+
+    // post_step() :83-107, after the step's observations and rewards are taken: a member that does
+    // not hold food picks up a live food it touches (the food is parked at -999), a dead food
+    // respawns at U(-0.95, 0.95)^2 (respawn_prob is 1), a member touching the good leader hands over.
+    template <class Pos, class P>
+    __device__ static __forceinline__ void post_step(Pos& pos, int* aux, const P& p, unsigned long long b) {
+        typedef decltype(pos[0].x) T;
+        int flags = aux[0];
+        bool at_leader[N_MEMBERS];
+#pragma unroll
+        for (int k = 0; k < N_MEMBERS; ++k)
+            at_leader[k] = touching<T>(pos[MEMBER0 + k], pos[GOOD_LEADER], p.size[MEMBER0 + k] + p.size[GOOD_LEADER]);
+#pragma unroll
+        for (int f = 0; f < N_FOOD; ++f) {
+            if ((flags >> f) & 1) {
+                bool taken = false;
+#pragma unroll
+                for (int k = 0; k < N_MEMBERS; ++k) {
+                    const bool pick = !taken && !((flags >> (3 + k)) & 1) &&
+                                      touching<T>(pos[FOOD0 + f], pos[MEMBER0 + k], p.size[FOOD0 + f] + p.size[MEMBER0 + k]);
+                    if (pick) { flags |= 1 << (3 + k); taken = true; }
+                }
+                if (taken) {
+                    flags &= ~(1 << f);
+                    pos[FOOD0 + f].x = T(-999); pos[FOOD0 + f].y = T(-999);
+                }
+            } else {
+                const V2<double> d = respawn_draw(aux[1], b, aux[2], 0.95);
+                aux[2] += 1;
+                pos[FOOD0 + f].x = (T)d.x; pos[FOOD0 + f].y = (T)d.y;
+                flags |= 1 << f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N_MEMBERS; ++k)
+            if (((flags >> (3 + k)) & 1) && at_leader[k]) flags &= ~(1 << (3 + k));
+        aux[0] = flags;
+    }
+
+    // reset_world :109-146: every food alive, nobody holds; a fresh respawn stream
+    template <class RS>
+    __host__ __device__ static int initial_aux(const RS& rs, unsigned long long b, int k) {
+        return k == 0 ? 7 : (k == 1 ? reset_stream_key(rs, b) : 0);
+    }
+
+    // reset_world :139-144: a food is redrawn until it touches neither the barrier nor a forest.
+    // d holds the float64 draws of all entities; p.size_d their float64 sizes.
+    template <class RS, class Pos, class P>
+    __host__ __device__ static void fix_reset(const RS& rs, unsigned long long b, Pos& d, const P& p) {
+        const int obst[3] = {BARRIER, FOREST0, FOREST0 + 1};
+        for (int f = FOOD0; f < FOOD0 + N_FOOD; ++f) {
+            for (int attempt = 1; attempt <= 64; ++attempt) {
+                bool bad = false;
+                for (int o = 0; o < 3; ++o) {
+                    const double dx = d[f].x - d[obst[o]].x, dy = d[f].y - d[obst[o]].y;
+                    bad = bad || (sqrt(dx * dx + dy * dy) < p.size_d[f] + p.size_d[obst[o]]);
+                }
+                if (!bad) break;
+                d[f] = reset_draw(rs, b, f, false, attempt);
+            }
         }
     }
 };

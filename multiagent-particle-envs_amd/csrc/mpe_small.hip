@@ -10,7 +10,8 @@ hipError_t launch_small_f64(const HostSpec& s, long long B, int mode, const Step
 bool small_supported(const HostSpec& s) {
     return (s.scenario == MPE_SCN_SPREAD && s.A == 3 && s.L == 3) || s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM ||
            s.scenario == MPE_SCN_SIMPLE || s.scenario == MPE_SCN_ADVERSARY || s.scenario == MPE_SCN_PUSH ||
-           s.scenario == MPE_SCN_SPEAKER_LISTENER || s.scenario == MPE_SCN_REFERENCE || s.scenario == MPE_SCN_CRYPTO;
+           s.scenario == MPE_SCN_SPEAKER_LISTENER || s.scenario == MPE_SCN_REFERENCE || s.scenario == MPE_SCN_CRYPTO ||
+           s.scenario == MPE_SCN_PREDATOR_PREY;
 }
 
 hipError_t launch_small(const HostSpec& s, long long B, int dtype, int mode, const StepArgs& a, hipStream_t st) {

@@ -164,19 +164,32 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 #pragma unroll
     for (int k = 0; k < NX; ++k) {      // goal landmark(s): drawn with the reset, otherwise the caller's
         if (MODE == MODE_ROLLOUT && rs.enabled) {
-            aux[k] = reset_aux(rs, (unsigned long long)b, k, Cfg::L);
+            aux[k] = Cfg::DYNAMIC ? Cfg::initial_aux(rs, (unsigned long long)b, k) : reset_aux(rs, (unsigned long long)b, k, Cfg::L);
             if (valid) aux_g[(long long)k * B + b] = aux[k];
         } else {
             aux[k] = aux_g[(long long)k * B + b];
         }
     }
-    if (MODE == MODE_ROLLOUT && rs.enabled) {
+    // Scenario.reset_world positions; a DYNAMIC scenario may redraw some until they are free
+    auto draw_world = [&](const ResetArgs& r) {
+        if (Cfg::DYNAMIC) {
+            V2<double> d[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const V2<double> d = reset_draw(rs, (unsigned long long)b, e, e < A);
-            pos[e].x = (T)d.x;
-            pos[e].y = (T)d.y;
+            for (int e = 0; e < E; ++e) d[e] = reset_draw(r, (unsigned long long)b, e, e < A);
+            Cfg::fix_reset(r, (unsigned long long)b, d, p);
+#pragma unroll
+            for (int e = 0; e < E; ++e) { pos[e].x = (T)d[e].x; pos[e].y = (T)d[e].y; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const V2<double> d = reset_draw(r, (unsigned long long)b, e, e < A);
+                pos[e].x = (T)d.x;
+                pos[e].y = (T)d.y;
+            }
         }
+    };
+    if (MODE == MODE_ROLLOUT && rs.enabled) {
+        draw_world(rs);
 #pragma unroll
         for (int i = 0; i < A; ++i) { vel[i].x = T(0); vel[i].y = T(0); }
         if (valid) {     // landmarks are not written back by the step loop: publish them now
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             for (int i = 0; i < A; ++i) {
                 if (Cfg::movable(i)) {
                     force[i] = decode_move<T>(act[col++], p.sens[i]);     // apply_action_force: u + 0
+                    if (Cfg::NEW_CORE) { force[i].x = p.force_scale[i] * force[i].x; force[i].y = p.force_scale[i] * force[i].y; }
                 } else {
                     force[i].x = T(0); force[i].y = T(0);
                 }
@@ -252,8 +266,34 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     const bool ma = a < A && Cfg::movable(a), mc = c < A && Cfg::movable(c);
                     if (!ma && !mc) continue;         // neither entity moves
                     const V2<T> f = contact_force<T>(pos[a], pos[c], p.size[a] + p.size[c], p.contact_force, p.contact_margin);
-                    if (ma) { force[a].x = f.x + force[a].x; force[a].y = f.y + force[a].y; }
-                    if (mc) { force[c].x = -f.x + force[c].x; force[c].y = -f.y + force[c].y; }
+                    if (Cfg::NEW_CORE && ma && mc) {
+                        // two movable entities share the force by their masses (new_core.py:290-294)
+                        const T ratio = p.mass[c] / p.mass[a], back = -(T(1) / ratio);
+                        force[a].x = ratio * f.x + force[a].x; force[a].y = ratio * f.y + force[a].y;
+                        force[c].x = back * f.x + force[c].x; force[c].y = back * f.y + force[c].y;
+                    } else {
+                        if (ma) { force[a].x = f.x + force[a].x; force[a].y = f.y + force[a].y; }
+                        if (mc) { force[c].x = -f.x + force[c].x; force[c].y = -f.y + force[c].y; }
+                    }
+                }
+            }
+            // ---- wall contact for every movable entity, after its entity contacts (core.py:182-188) ----
+            if (Cfg::N_WALLS > 0) {
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    if (!Cfg::movable(i)) continue;
+#pragma unroll
+                    for (int w = 0; w < Cfg::N_WALLS; ++w) {
+                        // further than 750 contact margins from the wall's face the softplus is exactly 0
+                        const T perp = p.wall_vertical[w] ? pos[i].x : pos[i].y;
+                        if (t_abs<T>(perp - p.wall_axis_pos[w]) - (p.size[i] + T(0.5) * p.wall_width[w]) > T(750) * p.contact_margin) continue;
+                        V2<T> wf;
+                        if (wall_force<T>(pos[i], p.size[i], p.ghost[i] != 0, p.wall_vertical[w] != 0, p.wall_hard[w] != 0, p.wall_axis_pos[w],
+                                          p.wall_end0[w], p.wall_end1[w], p.wall_width[w], p.contact_force, p.contact_margin, wf)) {
+                            force[i].x = force[i].x + wf.x;
+                            force[i].y = force[i].y + wf.y;
+                        }
+                    }
                 }
             }
             // ---- World.integrate_state ----
@@ -300,12 +340,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     const int epi = au.episode_count[b] + 1;
                     if (valid) au.episode_count[b] = epi;
                     const ResetArgs nr{1, au.seed, (unsigned long long)epi, au.landmark_lim};
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const V2<double> d = reset_draw(nr, (unsigned long long)b, e, e < A);
-                        pos[e].x = (T)d.x;
-                        pos[e].y = (T)d.y;
-                    }
+                    draw_world(nr);
 #pragma unroll
                     for (int i = 0; i < A; ++i) { vel[i].x = T(0); vel[i].y = T(0); }
                     if (NC > 0) {
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
 #pragma unroll
                     for (int k = 0; k < NX; ++k) {
-                        aux[k] = reset_aux(nr, (unsigned long long)b, k, Cfg::L);
+                        aux[k] = Cfg::DYNAMIC ? Cfg::initial_aux(nr, (unsigned long long)b, k) : reset_aux(nr, (unsigned long long)b, k, Cfg::L);
                         if (valid) aux_g[(long long)k * B + b] = aux[k];
                     }
                     if (valid) {
@@ -327,6 +362,9 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 }
             }
             Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
+            // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
+            // reset starts its episode untouched
+            if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !finished) Cfg::post_step(pos, aux, p, (unsigned long long)b);
         }
         __syncthreads();
         const long long row0 = (long long)t * B + env0;
@@ -359,6 +397,15 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 #pragma unroll
             for (int c = 0; c < NC; ++c) comm_g[(long long)c * B + b] = comm[c];
         }
+        if (Cfg::DYNAMIC) {     // post_step moves landmarks and rewrites the scenario's int state
+#pragma unroll
+            for (int e = A; e < E; ++e) {
+                pos_g[(long long)(2 * e) * B + b] = pos[e].x;
+                pos_g[(long long)(2 * e + 1) * B + b] = pos[e].y;
+            }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) aux_g[(long long)k * B + b] = aux[k];
+        }
     }
 }
 
@@ -377,6 +424,14 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     p.contact_force = (T)s.contact_force;
     p.contact_margin = (T)s.contact_margin;
     p.n_envs = n_envs;
+    for (int e = 0; e < Cfg::E; ++e) p.size_d[e] = s.size[e];
+    for (int i = 0; i < Cfg::A; ++i) { p.force_scale[i] = (T)s.force_scale[i]; p.ghost[i] = s.ghost[i]; }
+    for (int w = 0; w < SMALL_MAX_WALLS; ++w) {
+        const bool on = w < s.n_walls;
+        p.wall_axis_pos[w] = on ? (T)s.wall_axis_pos[w] : T(0); p.wall_end0[w] = on ? (T)s.wall_end0[w] : T(0);
+        p.wall_end1[w] = on ? (T)s.wall_end1[w] : T(0); p.wall_width[w] = on ? (T)s.wall_width[w] : T(0);
+        p.wall_vertical[w] = on ? s.wall_vertical[w] : 0; p.wall_hard[w] = on ? s.wall_hard[w] : 0;
+    }
     return p;
 }
 
@@ -394,7 +449,7 @@ template <typename T, class Cfg, bool CLAMP, int MODE, bool INFO, int EPW>
 static void launch_epw(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, const StepArgs& a, hipStream_t st) {
     const long long n_full = ((B & 3) == 0) ? (B / EPW) * EPW : 0;
     launch_range<T, Cfg, CLAMP, MODE, true, INFO, EPW>(p, 0, n_full, a, st);
-    launch_range<T, Cfg, CLAMP, MODE, false, INFO, 64>(p, n_full, B, a, st);
+    launch_range<T, Cfg, CLAMP, MODE, false, INFO, (EPW < 64 ? EPW : 64)>(p, n_full, B, a, st);
 }
 
 // Every launch uses 64-env tiles and one-wave workgroups.  Measured alternatives at 65 536 envs
@@ -408,7 +463,7 @@ static void launch_epw(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, con
 // the slow spot to other XCDs.
 template <typename T, class Cfg, bool CLAMP, int MODE, bool INFO>
 static void launch_mode(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, const StepArgs& a, hipStream_t st) {
-    launch_epw<T, Cfg, CLAMP, MODE, INFO, 64>(p, B, a, st);
+    launch_epw<T, Cfg, CLAMP, MODE, INFO, Cfg::template epw<T>()>(p, B, a, st);
 }
 
 template <typename T, class Cfg, bool CLAMP>
@@ -452,6 +507,8 @@ hipError_t launch_small_t(const HostSpec& s, long long B, int mode, const StepAr
             return launch_cfg<T, ReferenceCfg, true>(s, B, mode, a, st);
         case MPE_SCN_CRYPTO:
             return launch_cfg<T, CryptoCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_PREDATOR_PREY:
+            return launch_cfg<T, PredatorPreyCfg, true>(s, B, mode, a, st);
     }
     return hipErrorInvalidValue;
 }

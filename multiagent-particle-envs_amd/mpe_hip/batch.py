@@ -25,7 +25,8 @@ class BatchedEnv:
       pos   [2E, B]  env-minor entity coordinates (agents first)     vel  [2A, B]
       comm  [S*dim_c, B] comm state of the S speaking agents (or None)
       aux   [n_aux, B] int32: the landmark indices reset_world draws (goal landmark; goal_b of both agents in
-            simple_reference; goal and key in simple_crypto), or None
+            simple_reference; goal and key in simple_crypto), or the state simple_predator_prey's post_step
+            rewrites (row 0: bit f = food f alive, bit 3+k = member k holds food; rows 1-2: respawn stream), or None
       (worlds simulated by a whole wave -- ``env_major`` is True -- store these transposed:
       pos [B, 2E], vel [B, 2A], comm [B, S*dim_c]; use get_state / set_state to stay layout-agnostic)
       obs   [B, obs_total]; ``obs_n[i]`` is the view of agent i's columns

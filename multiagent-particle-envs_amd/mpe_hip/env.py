@@ -45,7 +45,8 @@ class MultiAgentEnv:
         owner = getattr(reward_callback, "__self__", None)
         cbs = [cb for cb in (reset_callback, reward_callback, observation_callback, info_callback) if cb is not None]
         self._scenario = owner if isinstance(owner, HipScenario) and all(getattr(cb, "__self__", None) is owner for cb in cbs) \
-            and observation_callback is not None and done_callback is None and not world.scripted_agents else None
+            and observation_callback is not None and done_callback is None and not world.scripted_agents \
+            and owner.fused_step and post_step_callback is None else None
 
         self.action_space, self.observation_space = [], []
         for agent in self.agents:

@@ -31,7 +31,11 @@ def spec_from_world(world, scenario_id, name):
                      adversary=np.array([bool(getattr(a, "adversary", False)) for a in ag]),
                      leader=np.array([bool(getattr(a, "leader", False)) for a in ag]),
                      dt=world.dt, damping=world.damping, contact_force=world.contact_force,
-                     contact_margin=world.contact_margin, name=name, collaborative=bool(getattr(world, "collaborative", False)))
+                     contact_margin=world.contact_margin, name=name, collaborative=bool(getattr(world, "collaborative", False)),
+                     walls=[dict(orient=w.orient, axis_pos=w.axis_pos, endpoints=tuple(w.endpoints), width=w.width, hard=w.hard)
+                            for w in world.walls],
+                     ghost=np.array([bool(getattr(a, "ghost", False)) for a in ag]), new_core=bool(getattr(world, "new_core", False)),
+                     accel=np.array([np.nan if a.accel is None else a.accel for a in ag], float))
 
 
 class HipScenario(BaseScenario):
@@ -44,6 +48,7 @@ class HipScenario(BaseScenario):
     obs_dtype = np.float64
     has_info = True          # the scenario defines benchmark_data
     fused_info = None        # ask the kernel for info_i / info_f (None: when has_info)
+    fused_step = True        # MultiAgentEnv.step may run the whole step as one fused launch
 
     def __init__(self):
         self._env = None        # (signature, BatchedEnv)

@@ -164,6 +164,24 @@ def crypto_spec():
                      adversary=np.array([True, False, False]), leader=np.zeros(3, bool), name="simple_crypto")
 
 
+ARENA_WALLS = tuple(dict(orient="H" if i % 2 == 0 else "V", axis_pos=-1.2 if i < 2 else 1.2, endpoints=(-1.2, 1.2), width=0.4, hard=True)
+                    for i in range(4))
+
+
+def predator_prey_spec():
+    """simple_predator_prey (multiagent/scenarios/simple_predator_prey.py:7-81) on the new_core physics:
+    3 adversaries (size .065, mass 2.25, max_speed 1; agent 0 leads) and 4 good agents (size .045, mass 1,
+    max_speed 1.3; agent 3 leads, 4-6 carry food); landmarks [barrier .2 (collides), food .03 x3, forest
+    .25 x2]; 4 hard walls of width .4 on the lines +-1.2; accel is None (default sensitivity 5)."""
+    adv = np.arange(7) < 3
+    return WorldSpec(_lib.SCN_PREDATOR_PREY, 7, 6, 3, size=np.r_[np.where(adv, 0.065, 0.045), [0.2, 0.03, 0.03, 0.03, 0.25, 0.25]],
+                     mass=np.r_[np.where(adv, 2.25, 1.0), np.ones(6)], movable=np.r_[np.ones(7, bool), np.zeros(6, bool)],
+                     collide=np.r_[np.ones(7, bool), [True, False, False, False, False, False]],
+                     sensitivity=np.full(7, 5.0), max_speed=np.where(adv, 1.0, 1.3), silent=np.ones(7, bool), adversary=adv,
+                     leader=(np.arange(7) == 0) | (np.arange(7) == 3), name="simple_predator_prey",
+                     walls=[dict(w) for w in ARENA_WALLS], ghost=np.zeros(7, bool), new_core=True, accel=np.full(7, np.nan))
+
+
 def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, walls=(), ghost=None,
                  movable=None, **world):
     """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158, or with
@@ -197,4 +215,6 @@ def make_spec(name, **kw):
         return reference_spec()
     if name == "simple_crypto":
         return crypto_spec()
+    if name == "simple_predator_prey":
+        return predator_prey_spec()
     raise ValueError("no batched kernel for scenario %r" % (name,))

@@ -42,6 +42,7 @@ SCN_PUSH = "simple_push"
 SCN_SPEAKER_LISTENER = "simple_speaker_listener"
 SCN_REFERENCE = "simple_reference"
 SCN_CRYPTO = "simple_crypto"
+SCN_PREDATOR_PREY = "simple_predator_prey"
 
 
 @dataclass
@@ -120,6 +121,9 @@ class Spec:
             return [2 + 2 * L + 3 + self.dim_c] * A
         if self.scenario == SCN_CRYPTO:
             return [self.dim_c, 2 * self.dim_c, 2 * self.dim_c]
+        if self.scenario == SCN_PREDATOR_PREY:
+            # vel, pos, own holding (members), others' pos and vel, members' holding, landmarks, in_forest
+            return [4 + 2 * (A - 1) * 2 + 3 + 2 * L + 2] * A
         raise ValueError(self.scenario)
 
 
@@ -228,7 +232,29 @@ def spec_crypto() -> Spec:
                 adversary=np.array([True, False, False]), leader=np.zeros(A, bool))
 
 
+ARENA_WALLS = [dict(orient="H" if i % 2 == 0 else "V", axis_pos=-1.2 if i < 2 else 1.2, endpoints=(-1.2, 1.2), width=0.4, hard=True)
+               for i in range(4)]
+
+
+def spec_predator_prey() -> Spec:
+    """simple_predator_prey.make_world, multiagent/scenarios/simple_predator_prey.py:7-81, on the
+    new_core physics: 3 adversaries (agent 0 leads) and 4 good agents (agent 3 leads; 4-6 are the
+    members that carry food); landmarks [barrier, food x3, forest x2]; 4 walls around the arena."""
+    A, L = 7, 6
+    adv = np.arange(A) < 3
+    size = np.concatenate([np.where(adv, 0.065, 0.045), [0.2, 0.03, 0.03, 0.03, 0.25, 0.25]])   # :39,49,58,67
+    mass = np.concatenate([np.where(adv, 2.25, 1.0), np.ones(L)])                              # :40
+    collide = np.array([True] * A + [True] + [False] * 5)                                       # :34,47,56,65
+    leader = (np.arange(A) == 0) | (np.arange(A) == 3)                                          # :35
+    return Spec(SCN_PREDATOR_PREY, A, L, 3, size, np.array([True] * A + [False] * L), collide, mass,
+                sens=np.full(A, 5.0), max_speed=np.where(adv, 1.0, 1.3), silent=np.ones(A, bool), adversary=adv, leader=leader,
+                food=[1, 2, 3], forests=[4, 5], walls=[dict(w) for w in ARENA_WALLS], ghost=np.zeros(A, bool),
+                new_core=True, accel=np.full(A, np.nan))
+
+
 def make_spec(name: str, **kw) -> Spec:
+    if name == SCN_PREDATOR_PREY:
+        return spec_predator_prey()
     if name == SCN_SPEAKER_LISTENER:
         return spec_speaker_listener()
     if name == SCN_REFERENCE:
@@ -777,3 +803,207 @@ def reset_with_goal(spec: Spec, rng: np.random.RandomState, B: int = 1):
         goal[b] = [rng.choice(spec.L), rng.choice(spec.L)] if two else rng.choice(spec.L)
         pos[b] = reset(spec, rng, 1)[0][0]
     return pos, np.zeros((B, spec.A, 2)), np.zeros((B, spec.A, spec.dim_c)), goal
+
+
+# --------------------------------------------------------------------------
+# simple_predator_prey (multiagent/scenarios/simple_predator_prey.py), on the new_core physics.
+# Beside pos / vel the world carries alive [B, 3] (food) and holding [B, 3] (the members, agents 4-6).
+# The scenario reads distances from the cache World.step fills (new_core.py:147-170):
+# cached_dist_vect[a, b] = p_a - p_b and its norm, the same bits as a direct evaluation.
+# --------------------------------------------------------------------------
+PP_MEMBERS = (4, 5, 6)
+PP_LEADER_GOOD = 3
+
+
+def pp_observe(spec: Spec, pos, vel, holding) -> List[np.ndarray]:
+    """observation(), simple_predator_prey.py:300-349 (cast to float32 at :349)."""
+    A, L = spec.A, spec.L
+    B = pos.shape[0]
+    f1, f2 = A + spec.forests[0], A + spec.forests[1]
+    inf = np.stack([np.stack([_is_collision(pos, i, f, spec.size) for f in (f1, f2)], axis=1) for i in range(A)], axis=1)
+    hold_val = np.where(holding, 1.0, -1.0)
+    out = []
+    for i in range(A):
+        parts = [vel[:, i, :], pos[:, i, :]]
+        if i in PP_MEMBERS:
+            parts.append(hold_val[:, PP_MEMBERS.index(i), None])
+        other_pos, other_vel, other_holding = [], [], []
+        for j in range(A):
+            if j == i:
+                continue
+            vis = (inf[:, i, 0] & inf[:, j, 0]) | (inf[:, i, 1] & inf[:, j, 1]) | \
+                  (~inf[:, i, 0] & ~inf[:, j, 0] & ~inf[:, i, 1] & ~inf[:, j, 1])
+            if spec.leader[i]:
+                vis = np.ones(B, bool)
+            other_pos.append(np.where(vis[:, None], pos[:, i, :] - pos[:, j, :], 0.0))     # cached_dist_vect[agent, other]
+            other_vel.append(np.where(vis[:, None], vel[:, j, :], 0.0))
+            if j in PP_MEMBERS:
+                other_holding.append(np.where(vis, hold_val[:, PP_MEMBERS.index(j)], 0.0)[:, None])
+        entity_pos = [pos[:, i, :] - pos[:, A + l, :] for l in range(L)]
+        in_forest = np.where(inf[:, i, :], 1.0, -1.0)
+        out.append(np.concatenate(parts + other_pos + other_vel + other_holding + entity_pos + [in_forest], axis=1).astype(np.float32))
+    return out
+
+
+def pp_reward(spec: Spec, pos, holding) -> np.ndarray:
+    """reward(), simple_predator_prey.py:171-275."""
+    A = spec.A
+    B = pos.shape[0]
+    advs = [i for i in range(A) if spec.adversary[i]]
+    good = [i for i in range(A) if not spec.adversary[i]]
+    foods = [A + f for f in spec.food]
+    dist = lambda a, b: _dist(pos[:, a, :] - pos[:, b, :])
+    hit = lambda a, b: _is_collision(pos, a, b, spec.size)
+    rew = np.zeros((B, A))
+    for i in range(A):
+        r = np.zeros(B)
+        if spec.adversary[i]:                                           # :243-275
+            r = r - 0.1 * np.stack([dist(i, g) for g in good], axis=0).min(axis=0)
+            n = np.zeros(B)
+            for g in good:
+                n = n + hit(i, g)
+            r = r + 5 * n
+            if spec.leader[i]:
+                for g in good:
+                    if g not in PP_MEMBERS:
+                        continue                                        # only members ever hold food
+                    n = np.zeros(B)
+                    for a in advs:
+                        n = n + hit(a, g)
+                    r = np.where(holding[:, PP_MEMBERS.index(g)], r + 10 * n, r)
+        else:                                                           # :183-241
+            s = np.zeros(B)
+            for a in advs:
+                s = s + dist(a, i)
+            r = r + 0.1 * s
+            n = np.zeros(B)
+            for a in advs:
+                n = n + hit(a, i)
+            r = r - 5 * n
+            if not spec.leader[i]:
+                h = holding[:, PP_MEMBERS.index(i)]
+                to_food = np.stack([dist(f, i) for f in foods], axis=0).min(axis=0)
+                r = np.where(h, r - 0.1 * dist(PP_LEADER_GOOD, i), r - 0.1 * to_food)
+            else:
+                d = np.stack([np.where(holding[:, k], dist(i, m), np.inf) for k, m in enumerate(PP_MEMBERS)], axis=0).min(axis=0)
+                r = np.where(holding.any(axis=1), r - 0.1 * d, r - 0)
+                for k, m in enumerate(PP_MEMBERS):
+                    nf = np.zeros(B)
+                    for f in foods:
+                        nf = nf + hit(f, m)
+                    r = np.where(holding[:, k], r + 5 * (hit(i, m) + 0.0), r + 5 * nf)
+        rew[:, i] = r
+    return rew
+
+
+def pp_info(spec: Spec, pos):
+    """benchmark_data(), simple_predator_prey.py:148-156: an adversary's collisions with good agents."""
+    A = spec.A
+    coll = np.zeros((pos.shape[0], A), np.int64)
+    for i in range(A):
+        if spec.adversary[i]:
+            for g in range(A):
+                if not spec.adversary[g]:
+                    coll[:, i] += _is_collision(pos, g, i, spec.size)
+    return {"collisions": coll}
+
+
+def pp_post_step(spec: Spec, pos, alive, holding, respawn_pos):
+    """post_step(), simple_predator_prey.py:83-107, with the distances World.step cached (i.e. of the
+    positions in ``pos`` on entry).  respawn_pos [B, 3, 2] is where a dead food reappears (the
+    reference draws U(-0.95, 0.95)^2; respawn_prob is 1).  Returns new (pos, alive, holding)."""
+    A = spec.A
+    pos = pos.copy()
+    alive = alive.copy()
+    holding = holding.copy()
+    hit_food = {(f, m): _is_collision(pos, A + spec.food[f], m, spec.size) for f in range(3) for m in PP_MEMBERS}
+    hit_leader = {m: _is_collision(pos, m, PP_LEADER_GOOD, spec.size) for m in PP_MEMBERS}
+    for f in range(3):
+        was_alive = alive[:, f].copy()
+        taken = np.zeros(pos.shape[0], bool)
+        for k, m in enumerate(PP_MEMBERS):
+            pick = was_alive & ~taken & ~holding[:, k] & hit_food[(f, m)]
+            holding[:, k] |= pick
+            taken |= pick
+        alive[:, f] = (was_alive & ~taken) | ~was_alive
+        e = A + spec.food[f]
+        pos[:, e, :] = np.where(taken[:, None], -999.0, np.where(was_alive[:, None], pos[:, e, :], respawn_pos[:, f, :]))
+    for k, m in enumerate(PP_MEMBERS):
+        holding[:, k] &= ~hit_leader[m]
+    return pos, alive, holding
+
+
+def pp_env_step(spec: Spec, pos, vel, actions, alive, holding, respawn_pos):
+    """MultiAgentEnv.step (environment.py:83-115) with the scenario's post_step as post_step_callback
+    (:107-108, run after the observations and rewards are taken).  Returns
+    (pos, vel, obs_list, rew, alive, holding)."""
+    u, c = decode_actions(spec, actions)
+    pos, vel, _ = world_step(spec, pos, vel, u, c)
+    obs = pp_observe(spec, pos, vel, holding)
+    rew = pp_reward(spec, pos, holding)
+    pos, alive, holding = pp_post_step(spec, pos, alive, holding, respawn_pos)
+    return pos, vel, obs, rew, alive, holding
+
+
+# --------------------------------------------------------------------------
+# The counter-based generator of the on-device reset and respawn: Philox-4x32-10 (Salmon et al.,
+# "Parallel random numbers: as easy as 1, 2, 3", SC'11), restated in numpy so that the device's
+# draws can be checked value for value.
+# --------------------------------------------------------------------------
+def philox4x32(key, ctr_lo, ctr_hi):
+    """Blocks for uint64 arrays key / ctr_lo / ctr_hi (broadcast together) -> uint32 [..., 4]."""
+    key, ctr_lo, ctr_hi = np.broadcast_arrays(np.asarray(key, np.uint64), np.asarray(ctr_lo, np.uint64), np.asarray(ctr_hi, np.uint64))
+    m32 = np.uint64(0xFFFFFFFF)
+    c = [ctr_lo & m32, ctr_lo >> np.uint64(32), ctr_hi & m32, ctr_hi >> np.uint64(32)]
+    k0, k1 = key & m32, key >> np.uint64(32)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & m32, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & m32]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def _u01(a, b):
+    """53-bit uniform in [0, 1) from two 32-bit words (numpy's random_sample construction)."""
+    return ((a.astype(np.uint64) >> np.uint64(5)) * np.uint64(67108864) + (b.astype(np.uint64) >> np.uint64(6))).astype(np.float64) / 9007199254740992.0
+
+
+def device_reset_draw(seed, b, episode, e, lim, attempt=0):
+    """Position of entity e of world(s) b: block (key seed, counter (b, episode * 256 + e + attempt << 48)),
+    mapped like numpy's uniform(-lim, lim)."""
+    r = philox4x32(seed, b, np.uint64(episode * 256 + e) + (np.uint64(attempt) << np.uint64(48)))
+    return np.stack([-lim + (lim + lim) * _u01(r[..., 0], r[..., 1]), -lim + (lim + lim) * _u01(r[..., 2], r[..., 3])], axis=-1)
+
+
+def device_aux_words(seed, b, episode):
+    """The block the landmark indices / stream key of world(s) b come from: counter (b, episode * 256 + 255)."""
+    return philox4x32(seed, b, np.uint64(episode * 256 + 255))
+
+
+def device_respawn_draw(key, b, n, lim=0.95):
+    """n-th respawn position of world(s) b with stream key `key` (int32 as stored in aux row 1)."""
+    k = np.uint64(0x5EED5EED00000000) | (np.asarray(key).astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF))
+    r = philox4x32(k, b, np.asarray(n).astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF))
+    return np.stack([-lim + (lim + lim) * _u01(r[..., 0], r[..., 1]), -lim + (lim + lim) * _u01(r[..., 2], r[..., 3])], axis=-1)
+
+
+def pp_device_reset(spec: Spec, seed, episode, B):
+    """simple_predator_prey worlds as the device reset draws them (foods redrawn until clear of the
+    barrier and the forests, simple_predator_prey.py:139-144).  Returns (pos [B, E, 2], stream key [B] int32)."""
+    A = spec.A
+    b = np.arange(B, dtype=np.uint64)
+    pos = np.stack([device_reset_draw(seed, b, episode, e, 1.0 if e < A else 0.9) for e in range(spec.E)], axis=1)
+    obst = [A, A + spec.forests[0], A + spec.forests[1]]
+    for f in spec.food:
+        e = A + f
+        for attempt in range(1, 65):
+            bad = np.zeros(B, bool)
+            for o in obst:
+                bad |= _dist(pos[:, e, :] - pos[:, o, :]) < spec.size[e] + spec.size[o]
+            if not bad.any():
+                break
+            pos[bad, e, :] = device_reset_draw(seed, b[bad], episode, e, 0.9, attempt)
+    key = device_aux_words(seed, b, episode)[:, 0].astype(np.int32)
+    return pos, key

@@ -199,3 +199,39 @@ def test_oracle_reproduces_reference_new_core_step():
         pos, vel, _ = orc.world_step(spec, pos, vel, u, c)
         assert np.array_equal(pos[:, :A], g["pos"][t]) and np.array_equal(vel, g["vel"][t]), t
     assert np.array_equal(g["pos"][-1][:, 6], g["pos0"][:, 6])      # the immovable agent stayed put
+
+
+def test_oracle_reproduces_predator_prey():
+    """simple_predator_prey through the reference's MultiAgentEnv.step (new_core physics, walls,
+    post_step pick-up / deposit / respawn), free-running for 25 steps with the respawn positions the
+    reference drew fed back in: state, observations, rewards, collisions and flags bit for bit."""
+    g = load_golden("simple_predator_prey")
+    spec = orc.make_spec("simple_predator_prey")
+    A = spec.A
+    assert spec.obs_dims == list(g["obs_dims"])
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    alive, holding = g["alive0"].copy(), g["holding0"].copy()
+    assert np.array_equal(np.concatenate(orc.pp_observe(spec, pos, vel, holding), axis=1), g["obs0"])
+    for t in range(g["actions"].shape[0]):
+        pos, vel, obs, rew, alive, holding = orc.pp_env_step(spec, pos, vel, g["actions"][t], alive, holding, g["food_pos"][t])
+        assert np.array_equal(pos[:, :A], g["pos"][t]), t
+        assert np.array_equal(vel, g["vel"][t]), t
+        assert np.array_equal(np.concatenate(obs, axis=1), g["obs"][t]), t
+        assert np.array_equal(rew, g["rew"][t]), t
+        assert np.array_equal(alive, g["alive"][t]) and np.array_equal(holding, g["holding"][t]), t
+        assert np.array_equal(pos[:, A + 1:A + 4], g["food_pos"][t]), t
+    # the fixture exercises the state machine
+    assert (~g["alive"]).sum() > 5 and g["holding"].sum() > 50 and g["collisions"].sum() > 10
+    # re-evaluate the collision counts on the recorded states
+    pos = g["pos0"].copy()
+    pos[:, :A] = g["pos"][-1]
+    assert np.array_equal(orc.pp_info(spec, pos)["collisions"], g["collisions"][-1])
+
+
+def test_philox_known_answers():
+    """Random123's published vectors for philox4x32-10 (counter words, key words -> output)."""
+    full = np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert [hex(x) for x in orc.philox4x32(0, 0, 0)] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in orc.philox4x32(full, full, full)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    pi = orc.philox4x32(np.uint64(0x299F31D0A4093822), np.uint64(0x85A308D3243F6A88), np.uint64(0x0370734413198A2E))
+    assert [hex(x) for x in pi] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]

@@ -31,6 +31,10 @@ Reference entry points used:
     simple_reference: both agents move and speak, so as for the simple_world_comm leader their
     ``action.u`` / ``action.c`` are written directly and ``World.step``, the callbacks and the
     reward sharing of environment.py:103-105 (``np.sum(reward_n)``) are called here.
+  * simple_predator_prey (new_core physics): ``MultiAgentEnv.step`` with the scenario's ``post_step``
+    as post_step_callback; it takes one argument (simple_predator_prey.py:83) where the env passes two
+    (environment.py:108), so it is wrapped.  Food respawns come from the global numpy generator; the
+    fixture records where each food went so that a replay can be fed the same positions.
   * simple_spread with 64 agents / 64 landmarks: the reference hard-codes 3/3
     (simple_spread.py:12-13); the world is assembled here from the reference's
     ``World/Agent/Landmark`` classes with the same property assignments
@@ -125,7 +129,7 @@ def load_reference():
     ref.environment = _load("multiagent.environment", os.path.join(REF, "multiagent", "environment.py"))
     ref.scenarios = {}
     for n in ("simple_spread", "simple_tag", "simple_world_comm", "simple", "simple_adversary", "simple_push",
-              "simple_speaker_listener", "simple_reference", "simple_crypto"):
+              "simple_speaker_listener", "simple_reference", "simple_crypto", "simple_predator_prey"):
         ref.scenarios[n] = _load("ref_scn_" + n, os.path.join(REF, "multiagent", "scenarios", n + ".py"))
     return ref
 
@@ -681,6 +685,102 @@ def run_comm(ref, name, seed, B=32):
     return pos0, vel0, actions, rec
 
 
+def run_predator_prey(ref, seed=20240641, B=32):
+    sc = ref.scenarios["simple_predator_prey"].Scenario()
+    world = sc.make_world()
+    env = ref.environment.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data,
+                                        post_step_callback=lambda w, rng: sc.post_step(w))
+    A, L = len(world.agents), len(world.landmarks)
+    assert (A, L) == (7, 6) and not env.shared_reward
+    rng = np.random.RandomState(seed)
+    pos0 = np.concatenate([rng.uniform(-1, 1, (B, A, 2)), rng.uniform(-0.9, 0.9, (B, L, 2))], axis=1)
+    vel0 = np.zeros((B, A, 2))
+    alive0 = np.ones((B, 3), bool)
+    holding0 = np.zeros((B, 3), bool)
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+    food = lambda f: A + 1 + f
+    forest = lambda f: A + 4 + f
+
+    def near(center, r):
+        ang = rng.uniform(0, 2 * np.pi)
+        return center + r * np.array([np.cos(ang), np.sin(ang)])
+
+    # envs 0..7: a member on / next to a food (pick-up distance 0.075); in 6 and 7 two members compete
+    for b in range(8):
+        d = [0.01, 0.05, 0.0749, 0.0751, 0.03, 0.07, 0.02, 0.04][b]
+        pos0[b, 4 + b % 3] = near(pos0[b, food(b % 3)], d)
+        actions[:3, b, 4 + b % 3] = 0
+        if b >= 6:
+            pos0[b, 4 + (b + 1) % 3] = near(pos0[b, food(b % 3)], d + 0.01)
+    # envs 8..11: a member holding food next to the good leader (deposit distance 0.09)
+    for k, b in enumerate(range(8, 12)):
+        holding0[b, k % 3] = True
+        pos0[b, 4 + k % 3] = near(pos0[b, 3], [0.02, 0.0899, 0.0901, 0.2][k])
+    # envs 12..15: food already eaten (parked at -999 until it respawns)
+    for k, b in enumerate(range(12, 16)):
+        alive0[b, k % 3] = False
+        pos0[b, food(k % 3)] = (-999.0, -999.0)
+        holding0[b, (k + 1) % 3] = True
+    # envs 16..19: forests kept apart, agents dealt into / out of them
+    for b in range(16, 20):
+        pos0[b, forest(0)], pos0[b, forest(1)] = (-0.5, -0.4), (0.5, 0.4)
+        for i in range(A):
+            where = (b + i * (1 + b % 3)) % 4
+            if where < 2:
+                pos0[b, i] = near(pos0[b, forest(where)], rng.uniform(0, 0.2))
+            elif where == 2:
+                pos0[b, i] = near(pos0[b, forest(0)], 0.25 + world.agents[i].size + rng.uniform(-0.02, 0.02))
+    # envs 20..23: an adversary on a member that holds food (contact distance 0.11), heavy on light
+    for k, b in enumerate(range(20, 24)):
+        holding0[b, k % 3] = True
+        pos0[b, k % 3] = near(pos0[b, 4 + k % 3], [0.03, 0.1099, 0.1101, 0.08][k])
+    # envs 24..27: agents at the walls, pushing outwards
+    for k, b in enumerate(range(24, 28)):
+        pos0[b, k] = [(-0.97, 0.3), (0.3, -0.99), (0.985, 0.2), (-0.2, 0.96)][k]
+        actions[:, b, k] = [1, 3, 2, 4][k]
+        pos0[b, 6] = [(0.99, 0.99), (-1.02, -0.98), (1.0, -1.0), (-0.96, 1.01)][k]
+    # envs 28..31: a moving cluster around the barrier
+    for b in range(28, 32):
+        for i in range(A):
+            pos0[b, i] = near(pos0[b, A], rng.uniform(0.2, 0.35))
+        vel0[b] = rng.uniform(-1, 1, (A, 2))
+    dims = [sp.shape[0] for sp in env.observation_space]
+    rec = {"pos": np.zeros((T_STEPS, B, A, 2)), "vel": np.zeros((T_STEPS, B, A, 2)),
+           "obs": np.zeros((T_STEPS, B, sum(dims))), "obs_dims": np.array(dims, np.int64),
+           "rew": np.zeros((T_STEPS, B, A)), "done": np.zeros((T_STEPS, B), np.uint8), "collisions": np.zeros((T_STEPS, B, A), np.int64),
+           "food_pos": np.zeros((T_STEPS, B, 3, 2)), "alive": np.zeros((T_STEPS, B, 3), bool), "holding": np.zeros((T_STEPS, B, 3), bool),
+           "obs0": np.zeros((B, sum(dims)))}
+    env.seed(0)
+    np.random.seed(seed)
+    for b in range(B):
+        env.reset()
+        inject(world, pos0[b], vel0[b])
+        for f, lm in enumerate(world.foods):
+            lm.alive = bool(alive0[b, f])
+        for k, m in enumerate(world.agents[4:]):
+            m.holding = bool(holding0[b, k])
+        world.calculate_distances()
+        rec["obs0"][b] = np.concatenate([np.asarray(sc.observation(a, world), np.float64) for a in world.agents])
+        for t in range(T_STEPS):
+            obs_n, rew_n, done, info_n = env.step([int(a) for a in actions[t, b]])
+            for i, ag in enumerate(world.agents):
+                rec["pos"][t, b, i] = ag.state.p_pos
+                rec["vel"][t, b, i] = ag.state.p_vel
+            rec["obs"][t, b] = np.concatenate([np.asarray(o, np.float64) for o in obs_n])
+            rec["rew"][t, b] = [float(r) for r in rew_n]
+            rec["done"][t, b] = bool(done)
+            rec["collisions"][t, b] = info_n["n"]
+            rec["food_pos"][t, b] = [f.state.p_pos for f in world.foods]
+            rec["alive"][t, b] = [f.alive for f in world.foods]
+            rec["holding"][t, b] = [m.holding for m in world.agents[4:]]
+    rec.update(alive0=alive0, holding0=holding0)
+    assert np.array_equal(rec["obs"].astype(np.float32), rec["obs"])        # the scenario casts to float32 (:349)
+    rec["obs"], rec["obs0"] = rec["obs"].astype(np.float32), rec["obs0"].astype(np.float32)
+    print("predator_prey: pick-ups", int((~rec["alive"]).sum()), "holding steps", int(rec["holding"].sum()),
+          "collisions", int(rec["collisions"].sum()))
+    return pos0, vel0, actions, rec
+
+
 def known_answers(ref):
     """Anchors that do not use state injection."""
     out = {}
@@ -759,6 +859,11 @@ def main():
     for name, seed in (("simple_speaker_listener", 20240621), ("simple_reference", 20240622), ("simple_crypto", 20240623)):
         pos0, vel0, actions, rec = run_comm(ref, name, seed)
         cases[name] = (name, {}, pos0, vel0, actions, rec)
+
+    pos0, vel0, actions, rec = run_predator_prey(ref)
+    np.savez_compressed(os.path.join(OUT, "simple_predator_prey.npz"), scenario=np.array("simple_predator_prey"), pos0=pos0, vel0=vel0,
+                        actions=actions.astype(np.int32), **rec)
+    print("wrote simple_predator_prey.npz")
 
     for key, (scn, kw, pos0, vel0, actions, rec) in cases.items():
         path = os.path.join(OUT, key + ".npz")
