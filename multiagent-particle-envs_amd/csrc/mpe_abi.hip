@@ -72,6 +72,14 @@ static const char* check_structure(const HostSpec& s) {
                     return "simple_predator_prey: 3 adversaries then 4 good agents, agents 0 and 3 lead, all collide and are silent";
             for (int l = 0; l < L; ++l)
                 if (s.collide[A + l] != (l == 0)) return "simple_predator_prey: only the barrier (first landmark) collides";
+            {   // the kernel reads one set of magnitudes per role
+                const int rep[13] = {0, 0, 0, 3, 3, 3, 3, 7, 8, 8, 8, 11, 11};
+                for (int e = 0; e < A + L; ++e)
+                    if (s.size[e] != s.size[rep[e]] || s.mass[e] != s.mass[rep[e]]) return "simple_predator_prey: size and mass must be uniform per role";
+                for (int i = 0; i < A; ++i)
+                    if (s.sens[i] != s.sens[rep[i]] || s.max_speed[i] != s.max_speed[rep[i]] || s.force_scale[i] != s.force_scale[rep[i]] || s.ghost[i] != s.ghost[rep[i]])
+                        return "simple_predator_prey: accel, max_speed and ghost must be uniform per role";
+            }
             return nullptr;
         case MPE_SCN_REFERENCE:
             if (A != 2 || L != 3 || s.dim_c != 10) return "simple_reference has 2 agents, 3 landmarks, dim_c 10";

@@ -106,6 +106,34 @@ __device__ __forceinline__ bool wall_force(V2<T> p, T size, bool ghost, bool ver
     return true;
 }
 
+// For kernels that test many (entity, wall) pairs: the usual case -- the entity lies between the
+// wall's ends, theta = 0 (core.py:299-302) -- is evaluated inline without trigonometry
+// (cos(0) * mag = mag, sin(0) * |mag| = 0 * |mag|); an entity sticking out past an end takes the
+// out-of-line general routine, so the kernel carries one copy of it instead of one per pair.
+template <typename T>
+__device__ __noinline__ bool wall_force_past_end(V2<T> p, T size, bool ghost, bool vertical, bool hard, T axis_pos, T end0, T end1, T width,
+                                                 T cf, T k, V2<T>& out) {
+    return wall_force<T>(p, size, ghost, vertical, hard, axis_pos, end0, end1, width, cf, k, out);
+}
+
+template <typename T>
+__device__ __forceinline__ bool wall_force_fast(V2<T> p, T size, bool ghost, bool vertical, bool hard, T axis_pos, T end0, T end1, T width,
+                                                T cf, T k, V2<T>& out) {
+    if (ghost && !hard) return false;
+    const T prll = vertical ? p.y : p.x, perp = vertical ? p.x : p.y;
+    if (prll < end0 - size || prll > end1 + size) return false;
+    if (prll < end0 || prll > end1) return wall_force_past_end<T>(p, size, ghost, vertical, hard, axis_pos, end0, end1, width, cf, k, out);
+    const T dist_min = size + T(0.5) * width;
+    const T delta = perp - axis_pos;
+    const T dist = t_abs<T>(delta);
+    const T pen = logaddexp0<T>(-(dist - dist_min) / k) * k;
+    const T mag = cf * delta / dist * pen;
+    const T f_prll = T(0) * t_abs<T>(mag);
+    out.x = vertical ? mag : f_prll;
+    out.y = vertical ? f_prll : mag;
+    return true;
+}
+
 // Scenario.is_collision: strict dist < size_1 + size_2 (simple_spread.py:77-81,
 // simple_tag.py:69-73, simple_world_comm.py:126-130).
 template <typename T> __device__ __forceinline__ bool touching(V2<T> p1, V2<T> p2, T dist_min) {

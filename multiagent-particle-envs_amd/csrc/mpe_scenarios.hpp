@@ -35,8 +35,15 @@ struct CfgBase {
     static constexpr bool DYNAMIC = false;  // ... or state post_step rewrites every step (then landmarks may move too)
     static constexpr bool NEW_CORE = false; // World.step of multiagent/new_core.py (mass-scaled action, mass-ratio contacts)
     static constexpr int N_WALLS = 0;
+    // > 1: the observation row is produced and streamed out in this many equal column chunks (one LDS
+    // tile of a chunk's width instead of the whole row), through observe_prepare / observe_chunk<C>
+    static constexpr int OBS_CHUNKS = 1;
     __host__ __device__ static constexpr bool movable(int) { return true; }    // Agent.movable
     __host__ __device__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
+    // Entity whose magnitudes (size, mass, sensitivity, speed limit ...) entity e shares: a scenario whose
+    // roles have uniform properties names one representative per role, so that the kernel reads a handful
+    // of parameters instead of one set per entity (mpe_create checks that the spec is uniform per role).
+    __host__ __device__ static constexpr int rep(int e) { return e; }
     // envs per wave: fewer when a 64-row observation tile does not fit the LDS
     template <typename T> __host__ __device__ static constexpr int epw() { return 64; }
     // hooks of scenarios with DYNAMIC state
@@ -664,8 +671,10 @@ struct PredatorPreyCfg : CfgBase {
     __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
     __host__ __device__ static constexpr bool leader(int i) { return i == 0 || i == GOOD_LEADER; }
     __host__ __device__ static constexpr bool member(int i) { return i >= MEMBER0; }
-    // a float64 tile of 64 x 315 observations is larger than the LDS
-    template <typename T> __host__ __device__ static constexpr int epw() { return sizeof(T) == 8 ? 32 : 64; }
+    // adversaries, good agents, the barrier, foods and forests each share their properties (:39-41,49,58,67)
+    __host__ __device__ static constexpr int rep(int e) { return e < N_ADV ? 0 : (e < A ? N_ADV : (e == BARRIER ? BARRIER : (e < FOREST0 ? FOOD0 : FOREST0))); }
+    // one agent's 45 values at a time: a 64 x 315 tile (80 KB in float32) would leave one wave per CU
+    static constexpr int OBS_CHUNKS = A;
 
     __device__ static __forceinline__ bool holds(int flags, int i) { return (flags >> (3 + i - MEMBER0)) & 1; }
 
@@ -675,7 +684,7 @@ struct PredatorPreyCfg : CfgBase {
         for (int i = 0; i < A; ++i)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-                inf[i][f] = touching<T>(pos[i], pos[FOREST0 + f], p.size[i] + p.size[FOREST0 + f]);
+                inf[i][f] = touching<T>(pos[i], pos[FOREST0 + f], p.size[rep(i)] + p.size[rep(FOREST0 + f)]);
     }
 
     // visibility test of simple_predator_prey.py:325
@@ -683,24 +692,41 @@ struct PredatorPreyCfg : CfgBase {
         return (i1 && o1) || (i2 && o2) || (!i1 && !o1 && !i2 && !o2) || leader(i);
     }
 
-    // observation() :300-349; offsets are cached_dist_vect[agent, other] = p_agent - p_other; cast to float32
+    // in_forest bits of every agent (bit 2i+f), shared by the chunks of one step's observation
     template <typename T, class P>
-    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, const P& p, T* row) {
+    __device__ static __forceinline__ int observe_prepare(const V2<T> (&pos)[E], const P& p) {
         bool inf[A][2];
         forest_bits<T>(pos, p, inf);
+        int bits = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) bits |= (inf[i][0] ? 1 : 0) << (2 * i) | (inf[i][1] ? 1 : 0) << (2 * i + 1);
+        return bits;
+    }
+
+    // observation() :300-349 of agents [I0, I1); offsets are cached_dist_vect[agent, other] = p_agent - p_other;
+    // cast to float32
+    template <typename T, int I0, int I1>
+    __device__ static __forceinline__ void observe_agents(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, int forest, T* row) {
+        bool inf[A][2];
+#pragma unroll
+        for (int i = 0; i < A; ++i) { inf[i][0] = (forest >> (2 * i)) & 1; inf[i][1] = (forest >> (2 * i + 1)) & 1; }
         const int flags = aux[0];
         int k = 0;
 #pragma unroll
-        for (int i = 0; i < A; ++i) {
+        for (int i = I0; i < I1; ++i) {
+            // A chunk is computed between the barriers that bracket its tile; pinning the agent's own position
+            // here keeps the compiler from hoisting every chunk's arithmetic (315 live values) above the first.
+            V2<T> me = pos[i];
+            if (I1 - I0 == 1) asm volatile("" : "+v"(me.x), "+v"(me.y));
             row[k++] = round_f32(vel[i].x); row[k++] = round_f32(vel[i].y);
-            row[k++] = round_f32(pos[i].x); row[k++] = round_f32(pos[i].y);
+            row[k++] = round_f32(me.x); row[k++] = round_f32(me.y);
             if (member(i)) row[k++] = holds(flags, i) ? T(1) : T(-1);
 #pragma unroll
             for (int j = 0; j < A; ++j) {
                 if (j == i) continue;
                 const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
-                row[k++] = vis ? round_f32(pos[i].x - pos[j].x) : T(0);
-                row[k++] = vis ? round_f32(pos[i].y - pos[j].y) : T(0);
+                row[k++] = vis ? round_f32(me.x - pos[j].x) : T(0);
+                row[k++] = vis ? round_f32(me.y - pos[j].y) : T(0);
             }
 #pragma unroll
             for (int j = 0; j < A; ++j) {
@@ -716,10 +742,20 @@ struct PredatorPreyCfg : CfgBase {
                 row[k++] = vis ? (holds(flags, j) ? T(1) : T(-1)) : T(0);
             }
 #pragma unroll
-            for (int l = 0; l < L; ++l) { row[k++] = round_f32(pos[i].x - pos[A + l].x); row[k++] = round_f32(pos[i].y - pos[A + l].y); }
+            for (int l = 0; l < L; ++l) { row[k++] = round_f32(me.x - pos[A + l].x); row[k++] = round_f32(me.y - pos[A + l].y); }
             row[k++] = inf[i][0] ? T(1) : T(-1);
             row[k++] = inf[i][1] ? T(1) : T(-1);
         }
+    }
+
+    template <typename T, int C>
+    __device__ static __forceinline__ void observe_chunk(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, int forest, T* row) {
+        observe_agents<T, C, C + 1>(pos, vel, aux, forest, row);
+    }
+
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, const P& p, T* row) {
+        observe_agents<T, 0, A>(pos, vel, aux, observe_prepare<T>(pos, p), row);
     }
 
     // reward() :171-275 and benchmark_data() :148-156
@@ -733,7 +769,7 @@ struct PredatorPreyCfg : CfgBase {
 #pragma unroll
             for (int a = 0; a < N_ADV; ++a) {
                 dist[g][a] = norm2<T>(pos[a].x - pos[g].x, pos[a].y - pos[g].y);
-                hit[g][a] = dist[g][a] < p.size[a] + p.size[g];
+                hit[g][a] = dist[g][a] < p.size[rep(a)] + p.size[rep(g)];
             }
 #pragma unroll
         for (int i = 0; i < A; ++i) {
@@ -798,9 +834,9 @@ struct PredatorPreyCfg : CfgBase {
                         if (!holds(flags, m)) {
 #pragma unroll
                             for (int f = 0; f < N_FOOD; ++f)
-                                c = c + (touching<T>(pos[FOOD0 + f], pos[m], p.size[FOOD0 + f] + p.size[m]) ? T(1) : T(0));
+                                c = c + (touching<T>(pos[FOOD0 + f], pos[m], p.size[rep(FOOD0 + f)] + p.size[rep(m)]) ? T(1) : T(0));
                         } else {
-                            c = touching<T>(pos[i], pos[m], p.size[i] + p.size[m]) ? T(1) : T(0);
+                            c = touching<T>(pos[i], pos[m], p.size[rep(i)] + p.size[rep(m)]) ? T(1) : T(0);
                         }
                         r = r + T(5) * c;
                     }
@@ -822,7 +858,7 @@ struct PredatorPreyCfg : CfgBase {
         bool at_leader[N_MEMBERS];
 #pragma unroll
         for (int k = 0; k < N_MEMBERS; ++k)
-            at_leader[k] = touching<T>(pos[MEMBER0 + k], pos[GOOD_LEADER], p.size[MEMBER0 + k] + p.size[GOOD_LEADER]);
+            at_leader[k] = touching<T>(pos[MEMBER0 + k], pos[GOOD_LEADER], p.size[rep(MEMBER0 + k)] + p.size[rep(GOOD_LEADER)]);
 #pragma unroll
         for (int f = 0; f < N_FOOD; ++f) {
             if ((flags >> f) & 1) {
@@ -830,7 +866,7 @@ struct PredatorPreyCfg : CfgBase {
 #pragma unroll
                 for (int k = 0; k < N_MEMBERS; ++k) {
                     const bool pick = !taken && !((flags >> (3 + k)) & 1) &&
-                                      touching<T>(pos[FOOD0 + f], pos[MEMBER0 + k], p.size[FOOD0 + f] + p.size[MEMBER0 + k]);
+                                      touching<T>(pos[FOOD0 + f], pos[MEMBER0 + k], p.size[rep(FOOD0 + f)] + p.size[rep(MEMBER0 + k)]);
                     if (pick) { flags |= 1 << (3 + k); taken = true; }
                 }
                 if (taken) {
@@ -866,7 +902,7 @@ struct PredatorPreyCfg : CfgBase {
                 bool bad = false;
                 for (int o = 0; o < 3; ++o) {
                     const double dx = d[f].x - d[obst[o]].x, dy = d[f].y - d[obst[o]].y;
-                    bad = bad || (sqrt(dx * dx + dy * dy) < p.size_d[f] + p.size_d[obst[o]]);
+                    bad = bad || (sqrt(dx * dx + dy * dy) < p.size_d[rep(f)] + p.size_d[rep(obst[o])]);
                 }
                 if (!bad) break;
                 d[f] = reset_draw(rs, b, f, false, attempt);

@@ -65,6 +65,30 @@ struct Tile {
     }
 };
 
+// Observation rows of a scenario that produces them in OBS_CHUNKS column chunks: every chunk is
+// written into the wave's (rows x chunk width) tile and streamed to its columns of the env-major
+// block at gbase (row stride OT), 4 bytes per lane.
+template <typename T, class Cfg, int C, int EPW>
+struct ObsChunks {
+    static constexpr int W = Cfg::OBS_TOTAL / Cfg::OBS_CHUNKS;
+    template <class Pos, class Vel, class Ctx>
+    static __device__ __forceinline__ void run(const Pos& pos, const Vel& vel, const int* aux, const Ctx& ctx, T* tile, T* gbase, int lane,
+                                               int tile_lane, bool active, int nvalid) {
+        if (active) Cfg::template observe_chunk<T, C>(pos, vel, aux, ctx, tile + tile_lane * W);
+        __syncthreads();
+        const int n = nvalid * W;
+#pragma unroll
+        for (int it = 0; it < (EPW * W + 63) / 64; ++it) {
+            const int g = it * 64 + lane;
+            const int r = g / W;
+            if (g < n) gbase[(long long)r * Cfg::OBS_TOTAL + C * W + (g - r * W)] = tile[g];
+        }
+        __syncthreads();
+        if constexpr (C + 1 < Cfg::OBS_CHUNKS)
+            ObsChunks<T, Cfg, C + 1, EPW>::run(pos, vel, aux, ctx, tile, gbase, lane, tile_lane, active, nvalid);
+    }
+};
+
 #ifdef MPE_STAMPS
 // Diagnostic build only: 100 MHz timestamps per workgroup (slot 0 start, 1 state and actions ready,
 // 2+t step t computed and its rows issued, 60 all steps done).  tools/probes/episode_stamps.py reads them.
@@ -90,8 +114,10 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
     constexpr int NI = Cfg::NI > 0 ? Cfg::NI : 1, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C, NX = Cfg::N_AUX;
     constexpr int NC = Cfg::S * Cfg::DIM_C;      // comm state values: the speakers' utterances in agent order
-    constexpr bool LIN = ((OT * (int)sizeof(T) / 4) % 16) != 0;
-    using ObsTile = Tile<T, OT, LIN, EPW>;
+    static_assert(OT % Cfg::OBS_CHUNKS == 0, "observation chunks are equal column ranges");
+    constexpr int OW = OT / Cfg::OBS_CHUNKS;        // columns held by the observation tile
+    constexpr bool LIN = Cfg::OBS_CHUNKS > 1 || ((OW * (int)sizeof(T) / 4) % 16) != 0;
+    using ObsTile = Tile<T, OW, LIN, EPW>;
     using RewTile = Tile<T, A, true, EPW>;
     using IiTile = Tile<int, NI, true, EPW>;
     using IfTile = Tile<T, NF, true, EPW>;
@@ -245,8 +271,8 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 #pragma unroll
             for (int i = 0; i < A; ++i) {
                 if (Cfg::movable(i)) {
-                    force[i] = decode_move<T>(act[col++], p.sens[i]);     // apply_action_force: u + 0
-                    if (Cfg::NEW_CORE) { force[i].x = p.force_scale[i] * force[i].x; force[i].y = p.force_scale[i] * force[i].y; }
+                    force[i] = decode_move<T>(act[col++], p.sens[Cfg::rep(i)]);     // apply_action_force: u + 0
+                    if (Cfg::NEW_CORE) { force[i].x = p.force_scale[Cfg::rep(i)] * force[i].x; force[i].y = p.force_scale[Cfg::rep(i)] * force[i].y; }
                 } else {
                     force[i].x = T(0); force[i].y = T(0);
                 }
@@ -265,10 +291,10 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     if (!Cfg::collides(a) || !Cfg::collides(c)) continue;
                     const bool ma = a < A && Cfg::movable(a), mc = c < A && Cfg::movable(c);
                     if (!ma && !mc) continue;         // neither entity moves
-                    const V2<T> f = contact_force<T>(pos[a], pos[c], p.size[a] + p.size[c], p.contact_force, p.contact_margin);
+                    const V2<T> f = contact_force<T>(pos[a], pos[c], p.size[Cfg::rep(a)] + p.size[Cfg::rep(c)], p.contact_force, p.contact_margin);
                     if (Cfg::NEW_CORE && ma && mc) {
                         // two movable entities share the force by their masses (new_core.py:290-294)
-                        const T ratio = p.mass[c] / p.mass[a], back = -(T(1) / ratio);
+                        const T ratio = p.mass[Cfg::rep(c)] / p.mass[Cfg::rep(a)], back = -(T(1) / ratio);
                         force[a].x = ratio * f.x + force[a].x; force[a].y = ratio * f.y + force[a].y;
                         force[c].x = back * f.x + force[c].x; force[c].y = back * f.y + force[c].y;
                     } else {
@@ -284,11 +310,14 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     if (!Cfg::movable(i)) continue;
 #pragma unroll
                     for (int w = 0; w < Cfg::N_WALLS; ++w) {
-                        // further than 750 contact margins from the wall's face the softplus is exactly 0
+                        // A wall further away than this contributes nothing: in float32 the softplus of
+                        // -(dist - dist_min) / k is exactly 0 beyond 16.7 k, in float64 it is below exp(-60),
+                        // i.e. a force under 1e-27 (the same reach as the contact loop of the large worlds)
                         const T perp = p.wall_vertical[w] ? pos[i].x : pos[i].y;
-                        if (t_abs<T>(perp - p.wall_axis_pos[w]) - (p.size[i] + T(0.5) * p.wall_width[w]) > T(750) * p.contact_margin) continue;
+                        const T cut = (sizeof(T) == 4 ? T(18) : T(60)) * p.contact_margin;
+                        if (t_abs<T>(perp - p.wall_axis_pos[w]) - (p.size[Cfg::rep(i)] + T(0.5) * p.wall_width[w]) > cut) continue;
                         V2<T> wf;
-                        if (wall_force<T>(pos[i], p.size[i], p.ghost[i] != 0, p.wall_vertical[w] != 0, p.wall_hard[w] != 0, p.wall_axis_pos[w],
+                        if (wall_force_fast<T>(pos[i], p.size[Cfg::rep(i)], p.ghost[Cfg::rep(i)] != 0, p.wall_vertical[w] != 0, p.wall_hard[w] != 0, p.wall_axis_pos[w],
                                           p.wall_end0[w], p.wall_end1[w], p.wall_width[w], p.contact_force, p.contact_margin, wf)) {
                             force[i].x = force[i].x + wf.x;
                             force[i].y = force[i].y + wf.y;
@@ -299,7 +328,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             // ---- World.integrate_state ----
 #pragma unroll
             for (int i = 0; i < A; ++i)
-                if (Cfg::movable(i)) integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[i], p.max_speed[i], p.one_minus_damping, p.dt);
+                if (Cfg::movable(i)) integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[Cfg::rep(i)], p.max_speed[Cfg::rep(i)], p.one_minus_damping, p.dt);
         }
 
         // ---- scenario callbacks into the wave's LDS tiles ----
@@ -361,14 +390,17 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
                 }
             }
-            Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
-            // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
-            // reset starts its episode untouched
-            if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !finished) Cfg::post_step(pos, aux, p, (unsigned long long)b);
+            if constexpr (Cfg::OBS_CHUNKS == 1) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
         }
-        __syncthreads();
         const long long row0 = (long long)t * B + env0;
-        ObsTile::template flush<FULL>(tile_obs, obs_g + row0 * OT, lane, nvalid);
+        if constexpr (Cfg::OBS_CHUNKS > 1)
+            ObsChunks<T, Cfg, 0, EPW>::run(pos, vel, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_g + row0 * OT, lane, tile_lane,
+                                           EPW == 64 || lane < EPW, nvalid);
+        // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
+        // reset starts its episode untouched
+        if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, (unsigned long long)b);
+        __syncthreads();
+        if constexpr (Cfg::OBS_CHUNKS == 1) ObsTile::template flush<FULL>(tile_obs, obs_g + row0 * OT, lane, nvalid);
         if (want_score) {
             RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane, nvalid);
             if (MODE != MODE_OBSERVE && valid) done_g[row0 + lane] = finished ? 1 : 0;

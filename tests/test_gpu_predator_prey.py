@@ -186,6 +186,7 @@ def test_free_running_episode_against_oracle(mode):
             gp, gv, _ = env.get_state()
             assert _close(gp, pos, 1e-9, 1e-12) and _close(gv, vel, 1e-9, 1e-12), t
             assert np.array_equal(env.aux[0].cpu().numpy(), _flags(alive, holding)) and np.array_equal(env.aux[2].cpu().numpy(), count)
+            assert np.array_equal(ii.cpu().numpy()[:, :A], orc.pp_info(spec, pos)["collisions"])      # agents do not move in post_step
         else:
             g_obs, g_rew = out["obs"][t].cpu().numpy(), out["rew"][t].cpu().numpy()
         assert _close(g_obs, np.concatenate(obs, axis=1), 1e-9, 1e-12), (mode, t)
