@@ -403,7 +403,22 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
         if constexpr (Cfg::OBS_CHUNKS == 1) ObsTile::template flush<FULL>(tile_obs, obs_g + row0 * OT, lane, nvalid);
         if (want_score) {
             RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane, nvalid);
-            if (MODE != MODE_OBSERVE && valid) done_g[row0 + lane] = finished ? 1 : 0;
+            if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
+                // No scenario ends an episode (environment.py:143-146) and a rollout has no time limit, so
+                // done is 0 throughout.  A wave's 64 flags are half a 128-byte line: neighbouring waves take
+                // turns (even steps the even wave, odd steps the odd one) to write both halves as one
+                // full line; a last wave without a neighbour writes its own half.
+                const long long pair0 = env_begin + (long long)(blockIdx.x & ~1u) * 64;
+                const bool paired = pair0 + 128 <= env_end;
+                if (paired) {
+                    if (((unsigned)t & 1u) == (blockIdx.x & 1u) && lane < 32)
+                        reinterpret_cast<unsigned*>(done_g + (long long)t * B + pair0)[lane] = 0u;
+                } else {
+                    done_g[row0 + lane] = 0;
+                }
+            } else if (MODE != MODE_OBSERVE && valid) {
+                done_g[row0 + lane] = finished ? 1 : 0;
+            }
             if (want_info) {
                 IiTile::template flush<FULL>(tile_ii, info_i_g + row0 * NI, lane, nvalid);
                 if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::template flush<FULL>(tile_if, info_f_g + row0 * NF, lane, nvalid);
