@@ -21,7 +21,12 @@
  * agents first, then landmarks -- the order of World.entities, multiagent/core.py:127-129)
  *   pos      T[2E][B]        row 2e+d holds coordinate d of entity e for every env (env-minor)
  *   vel      T[2A][B]        same for agent velocities (landmarks never move)
- *   comm     T[S*dim_c][B]   state.c of the S non-silent agents, in agent order (may be NULL if S == 0)
+ *   comm     T[S*dim_c][B]   state.c of the S non-silent agents, in agent order (may be NULL if S == 0).
+ *                            consensus (no speakers) keeps its history here instead, MpeLayout.n_hist_rows
+ *                            = 10 * A * 4 rows: state.p_his_pos / p_his_vel (new_core.py:252-254) as a ring of
+ *                            ten slots, row (slot * A + agent) * 4 + {0: x, 1: y, 2: vx, 3: vy}; aux row 0 is
+ *                            the slot holding the oldest entry (history entry k, oldest first, is slot
+ *                            (aux + k) % 10)
  *   aux      int32[n_aux][B] landmark indices reset_world draws besides positions and keeps for the
  *                            episode (may be NULL if n_aux == 0): row 0 is the goal landmark
  *                            (agent.goal_a) in simple_adversary and simple_push and the listener's
@@ -79,12 +84,13 @@ extern "C" {
 #define MPE_SCN_REFERENCE 8  /* multiagent/scenarios/simple_reference.py */
 #define MPE_SCN_CRYPTO 9     /* multiagent/scenarios/simple_crypto.py */
 #define MPE_SCN_PREDATOR_PREY 10 /* multiagent/scenarios/simple_predator_prey.py (on multiagent/new_core.py) */
+#define MPE_SCN_CONSENSUS 11 /* multiagent/scenarios/consensus.py (on multiagent/new_core.py) */
 
 /* World.step variants (MpeSpec.physics) */
 #define MPE_PHYSICS_CORE 0     /* multiagent/core.py:142-233 */
 #define MPE_PHYSICS_NEW_CORE 1 /* multiagent/new_core.py:188-298: action force scaled by mass (* accel) (:214),
                                   contact between two movable entities split by their mass ratio (:290-294);
-                                  MPE_SCN_NONE (mpe_world_step) and MPE_SCN_PREDATOR_PREY */
+                                  MPE_SCN_NONE (mpe_world_step), MPE_SCN_PREDATOR_PREY, MPE_SCN_CONSENSUS */
 
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_LANDMARKS 64
@@ -162,6 +168,8 @@ typedef struct MpeLayout {
     int32_t n_aux;       /* rows of aux */
     int32_t obs_dim[MPE_MAX_AGENTS];
     int32_t obs_offset[MPE_MAX_AGENTS];
+    int32_t n_hist_rows; /* rows of history state kept in the comm buffer (consensus), else 0 */
+    int32_t reserved;
 } MpeLayout;
 
 typedef struct MpeHandle MpeHandle;
@@ -198,6 +206,7 @@ int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* c
  * mpe_reset(h, seed, episode_count[b], ...), so obs holds the first observation of the new episode
  * (rew and info still describe the step that ended the old one).  All four bookkeeping arrays are
  * caller-owned device buffers, zero-initialised by the caller before the first episode.
+ * Not available for consensus (MPE_ERR_UNSUPPORTED): reset it with mpe_reset or run mpe_episode.
  */
 int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux,
                   void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t* step_count,

@@ -42,7 +42,7 @@ static const char* check_structure(const HostSpec& s) {
     const int A = s.A, L = s.L;
     for (int l = 0; l < L; ++l)
         if (s.movable[A + l]) return "landmarks must not be movable";
-    const bool shared = s.scenario == MPE_SCN_SPEAKER_LISTENER || s.scenario == MPE_SCN_REFERENCE;
+    const bool shared = s.scenario == MPE_SCN_SPEAKER_LISTENER || s.scenario == MPE_SCN_REFERENCE || s.scenario == MPE_SCN_CONSENSUS;
     if (s.scenario != MPE_SCN_NONE && (s.collaborative != 0) != shared)
         return shared ? "the scenario shares rewards: collaborative must be 1" : "the scenario does not share rewards: collaborative must be 0";
     switch (s.scenario) {
@@ -64,6 +64,15 @@ static const char* check_structure(const HostSpec& s) {
         if (!s.movable[i] && s.scenario != MPE_SCN_NONE) return "agents must be movable";
     switch (s.scenario) {
         case MPE_SCN_NONE:
+            return nullptr;
+        case MPE_SCN_CONSENSUS:
+            if (A != 6 || L != 0 || s.n_walls != 4) return "consensus has 6 agents, no landmarks and 4 walls";
+            for (int i = 0; i < A; ++i) {
+                if (s.collide[i] || !s.silent[i] || !s.movable[i]) return "consensus agents move, are silent and do not collide";
+                if (s.size[i] != s.size[0] || s.mass[i] != s.mass[0] || s.sens[i] != s.sens[0] || s.force_scale[i] != s.force_scale[0] ||
+                    s.ghost[i] != s.ghost[0] || isfinite(s.max_speed[i]))
+                    return "consensus agents share size, mass, accel and ghost and have no speed limit";
+            }
             return nullptr;
         case MPE_SCN_PREDATOR_PREY:
             if (A != 7 || L != 6 || s.n_walls != 4) return "simple_predator_prey has 7 agents, 6 landmarks and 4 walls";
@@ -162,6 +171,7 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
             case MPE_SCN_REFERENCE: d = 2 + 2 * L + 3 + s.dim_c; break;
             case MPE_SCN_CRYPTO: d = (i == 0) ? s.dim_c : 2 * s.dim_c; break;
             case MPE_SCN_PREDATOR_PREY: d = 4 + 4 * (A - 1) + 3 + 2 * L + 2; break;
+            case MPE_SCN_CONSENSUS: d = 2 * 2 * 10 * 2; break;
             default: d = 0;
         }
         lo->obs_dim[i] = d;
@@ -181,6 +191,7 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
         default: break;
     }
     lo->n_aux = s.n_aux();
+    lo->n_hist_rows = (s.scenario == MPE_SCN_CONSENSUS) ? 10 * A * 4 : 0;
 }
 
 extern "C" {
@@ -206,11 +217,12 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     s.scenario = spec->scenario; s.A = A; s.L = L; s.dim_c = spec->dim_c; s.collaborative = spec->collaborative ? 1 : 0;
     s.physics = spec->physics;
     if (s.physics != MPE_PHYSICS_CORE && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: unknown physics %d", s.physics); }
-    if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE && spec->scenario != MPE_SCN_PREDATOR_PREY) {
+    const bool new_core_scn = spec->scenario == MPE_SCN_PREDATOR_PREY || spec->scenario == MPE_SCN_CONSENSUS;
+    if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE && !new_core_scn) {
         delete h;
-        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step (MPE_SCN_NONE) and simple_predator_prey only");
+        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey and consensus only");
     }
-    if (spec->scenario == MPE_SCN_PREDATOR_PREY && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: simple_predator_prey runs on the new_core physics"); }
+    if (new_core_scn && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: this scenario runs on the new_core physics"); }
     if (s.physics == MPE_PHYSICS_NEW_CORE && !spec->accel) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: new_core physics needs the accel array"); }
     s.dt = spec->dt; s.damping = spec->damping; s.contact_force = spec->contact_force; s.contact_margin = spec->contact_margin;
     for (int e = 0; e < A + L; ++e) {
@@ -231,7 +243,7 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     s.n_walls = spec->n_walls;
     if (s.n_walls < 0 || s.n_walls > MPE_MAX_WALLS) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: 0..%d walls (got %d)", MPE_MAX_WALLS, spec->n_walls); }
     if (s.n_walls > 0) {
-        if (spec->scenario != MPE_SCN_NONE && spec->scenario != MPE_SCN_PREDATOR_PREY) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: walls are simulated by mpe_world_step (MPE_SCN_NONE) and simple_predator_prey only"); }
+        if (spec->scenario != MPE_SCN_NONE && !new_core_scn) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: walls are simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey and consensus only"); }
         if (!spec->wall_vertical || !spec->wall_axis_pos || !spec->wall_end0 || !spec->wall_end1 || !spec->wall_width || !spec->wall_hard) {
             delete h;
             return fail(nullptr, MPE_ERR_INVALID, "mpe_create: a wall array is NULL");
@@ -253,7 +265,7 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     h->dtype = dtype;
     h->device = device;
     fill_layout(s, n_envs, &h->layout);
-    h->use_wave = !small_supported(s);
+    h->use_wave = !small_supported(s) && s.scenario != MPE_SCN_CONSENSUS;
     if (h->use_wave && !wave_supported(s)) {
         delete h;
         return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: no kernel for scenario %d with %d agents / %d landmarks", s.scenario, A, L);
@@ -303,7 +315,10 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
     if (!h) return MPE_ERR_INVALID;
     if (h->spec.scenario == MPE_SCN_NONE) return fail(h, MPE_ERR_INVALID, "%s: handle was created with MPE_SCN_NONE; use mpe_world_step", who);
     if (!a.pos || !a.vel || !a.obs) return fail(h, MPE_ERR_INVALID, "%s: pos, vel and obs must not be NULL", who);
-    if (h->layout.n_speakers > 0 && !a.comm) return fail(h, MPE_ERR_INVALID, "%s: comm must not be NULL for a scenario with speaking agents", who);
+    if ((h->layout.n_speakers > 0 || h->layout.n_hist_rows > 0) && !a.comm)
+        return fail(h, MPE_ERR_INVALID, "%s: comm must not be NULL for a scenario with speaking agents or a history", who);
+    if (h->spec.scenario == MPE_SCN_CONSENSUS && (a.au.step_count != nullptr || a.info_i != nullptr))
+        return fail(h, MPE_ERR_UNSUPPORTED, "%s: consensus has neither mpe_step_auto nor benchmark outputs", who);
     if (mode != 2 && (!a.actions || !a.rew || !a.done)) return fail(h, MPE_ERR_INVALID, "%s: actions, rew and done must not be NULL", who);
     if (mode == 1 && a.n_steps < 1) return fail(h, MPE_ERR_INVALID, "%s: n_steps must be >= 1", who);
     if (a.info_f && !a.info_i) return fail(h, MPE_ERR_INVALID, "%s: info_f requires info_i", who);
@@ -315,8 +330,9 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
         if (((uintptr_t)ptr & 15u) != 0) return fail(h, MPE_ERR_INVALID, "%s: every buffer must be 16-byte aligned (got %p)", who, ptr);
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
-    e = h->use_wave ? launch_wave(h->spec, h->table, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream)
-                    : launch_small(h->spec, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream);
+    e = h->spec.scenario == MPE_SCN_CONSENSUS ? launch_consensus(h->spec, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream)
+        : h->use_wave                           ? launch_wave(h->spec, h->table, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream)
+                                                : launch_small(h->spec, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, who);
     return MPE_OK;
 }
@@ -369,11 +385,14 @@ int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask
     if (!h) return MPE_ERR_INVALID;
     if (!pos || !vel) return fail(h, MPE_ERR_INVALID, "mpe_reset: pos and vel must not be NULL");
     const int comm_rows = h->layout.n_speakers * h->spec.dim_c;
-    if (comm_rows > 0 && !comm) return fail(h, MPE_ERR_INVALID, "mpe_reset: comm must not be NULL for a scenario with speaking agents");
+    if ((comm_rows > 0 || h->layout.n_hist_rows > 0) && !comm)
+        return fail(h, MPE_ERR_INVALID, "mpe_reset: comm must not be NULL for a scenario with speaking agents or a history");
     if (h->layout.n_aux > 0 && !aux) return fail(h, MPE_ERR_INVALID, "mpe_reset: aux must not be NULL for a scenario with a goal landmark");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
-    e = launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, h->use_wave, seed, episode, mask, pos, vel, comm, aux, (hipStream_t)stream);
+    e = h->spec.scenario == MPE_SCN_CONSENSUS
+            ? launch_consensus_reset(h->spec, h->layout.n_envs, h->dtype, seed, episode, mask, pos, vel, comm, aux, (hipStream_t)stream)
+            : launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, h->use_wave, seed, episode, mask, pos, vel, comm, aux, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, "mpe_reset");
     return MPE_OK;
 }

@@ -26,7 +26,7 @@ struct HostSpec {
     // rows of per-episode scenario state: the landmark indices reset_world draws
     int n_aux() const {
         switch (scenario) {
-            case MPE_SCN_ADVERSARY: case MPE_SCN_PUSH: case MPE_SCN_SPEAKER_LISTENER: return 1;
+            case MPE_SCN_ADVERSARY: case MPE_SCN_PUSH: case MPE_SCN_SPEAKER_LISTENER: case MPE_SCN_CONSENSUS: return 1;
             case MPE_SCN_REFERENCE: case MPE_SCN_CRYPTO: return 2;
             case MPE_SCN_PREDATOR_PREY: return 3;
             default: return 0;
@@ -95,6 +95,11 @@ namespace mpe {
 // on-device reset_world (mpe_reset.hip); env_major selects the state layout
 hipError_t launch_reset(const HostSpec& s, long long n_envs, int dtype, int comm_rows, bool env_major, unsigned long long seed,
                         unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, int32_t* aux, hipStream_t st);
+
+// consensus (mpe_consensus.hip): a.comm is the history ring, a.aux its head; mode: 0 step, 1 rollout, 2 observe
+hipError_t launch_consensus(const HostSpec& s, long long n_envs, int dtype, int mode, const StepArgs& a, hipStream_t st);
+hipError_t launch_consensus_reset(const HostSpec& s, long long n_envs, int dtype, unsigned long long seed, unsigned long long episode,
+                                  const uint8_t* mask, void* pos, void* vel, void* hist, int32_t* aux, hipStream_t st);
 
 // wave-per-world kernels (mpe_wave.hip), env-major state; mode: 0 step, 1 rollout, 2 observe
 bool wave_supported(const HostSpec& s);

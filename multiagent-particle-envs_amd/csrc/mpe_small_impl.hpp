@@ -338,13 +338,13 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             if (want_score)
                 Cfg::template score<T>(pos, comm, aux, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
             if (Cfg::SHARED && MODE != MODE_OBSERVE) {
-                // collaborative world: step hands every agent np.sum(reward_n) (environment.py:103-105),
-                // the first reward plus the running sum of the others
+                // collaborative world: step hands every agent np.sum(reward_n) (environment.py:103-105);
+                // numpy adds fewer than 8 values left to right
+                static_assert(!Cfg::SHARED || A < 8, "np.sum switches to pairwise blocks at 8 values");
                 T* rrow = RewTile::row(tile_rew, tile_lane);
-                T rest = rrow[A > 1 ? 1 : 0];
+                T total = rrow[0];
 #pragma unroll
-                for (int i = 2; i < A; ++i) rest = rest + rrow[i];
-                const T total = A > 1 ? rrow[0] + rest : rrow[0];
+                for (int i = 1; i < A; ++i) total = total + rrow[i];
 #pragma unroll
                 for (int i = 0; i < A; ++i) rrow[i] = total;
             }

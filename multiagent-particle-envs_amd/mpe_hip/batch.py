@@ -69,7 +69,8 @@ class BatchedEnv:
         st = (lambda rows: z(B, rows)) if self.env_major else (lambda rows: z(rows, B))
         self.pos = st(2 * (A + L))
         self.vel = st(2 * A)
-        self.comm = st(lo.n_speakers * lo.dim_c) if lo.n_speakers > 0 else None
+        comm_rows = lo.n_speakers * lo.dim_c + lo.n_hist_rows       # consensus keeps its history ring in the comm buffer
+        self.comm = st(comm_rows) if comm_rows > 0 else None
         self.aux = z(lo.n_aux, B, dt=torch.int32) if lo.n_aux > 0 else None
         self.obs = z(B, lo.obs_total)
         self.rew = z(B, A)
@@ -213,6 +214,26 @@ class BatchedEnv:
         vel = lay(self.vel).reshape(B, A, 2).cpu().numpy()
         comm = lay(self.comm).cpu().numpy() if self.comm is not None else None
         return pos, vel, comm
+
+    def set_history(self, his_pos, his_vel):
+        """consensus: the agents' last ten positions and velocities, [B, A, 10, 2] each, oldest first
+        (state.p_his_pos / p_his_vel); stored as the history ring with its head at slot 0."""
+        if self.layout.n_hist_rows == 0:
+            raise ValueError("this scenario keeps no history")
+        B, A = self.n_envs, self.n_agents
+        h = np.concatenate([np.asarray(his_pos, np.float64), np.asarray(his_vel, np.float64)], axis=3)     # [B, A, 10, 4]
+        rows = torch.as_tensor(h.transpose(0, 2, 1, 3).reshape(B, -1), dtype=self.dtype)                  # (slot, agent, component)
+        self.comm.copy_(rows.t().contiguous())
+        self.aux.zero_()
+
+    def get_history(self):
+        """consensus: (his_pos, his_vel) [B, A, 10, 2], oldest first."""
+        B, A = self.n_envs, self.n_agents
+        ring = self.comm.t().reshape(B, 10, A, 4).cpu().numpy()
+        head = self.aux[0].cpu().numpy()
+        order = (head[:, None] + np.arange(10)[None, :]) % 10
+        h = ring[np.arange(B)[:, None], order].transpose(0, 2, 1, 3)
+        return h[..., :2].copy(), h[..., 2:].copy()
 
     @property
     def goal(self):

@@ -182,6 +182,15 @@ def predator_prey_spec():
                      walls=[dict(w) for w in ARENA_WALLS], ghost=np.zeros(7, bool), new_core=True, accel=np.full(7, np.nan))
 
 
+def consensus_spec():
+    """consensus (multiagent/scenarios/consensus.py:8-44) on the new_core physics: 6 silent, non-colliding
+    ghost agents of size .03 inside the 4 hard arena walls, no landmarks, shared rewards."""
+    return WorldSpec(_lib.SCN_CONSENSUS, 6, 0, 2, size=np.full(6, 0.03), mass=np.ones(6), movable=np.ones(6, bool),
+                     collide=np.zeros(6, bool), sensitivity=np.full(6, 5.0), max_speed=np.full(6, np.inf), silent=np.ones(6, bool),
+                     adversary=np.zeros(6, bool), leader=np.zeros(6, bool), name="consensus", walls=[dict(w) for w in ARENA_WALLS],
+                     ghost=np.ones(6, bool), new_core=True, accel=np.full(6, np.nan), collaborative=True)
+
+
 def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, walls=(), ghost=None,
                  movable=None, **world):
     """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158, or with
@@ -217,4 +226,6 @@ def make_spec(name, **kw):
         return crypto_spec()
     if name == "simple_predator_prey":
         return predator_prey_spec()
+    if name == "consensus":
+        return consensus_spec()
     raise ValueError("no batched kernel for scenario %r" % (name,))

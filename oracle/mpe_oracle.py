@@ -43,6 +43,7 @@ SCN_SPEAKER_LISTENER = "simple_speaker_listener"
 SCN_REFERENCE = "simple_reference"
 SCN_CRYPTO = "simple_crypto"
 SCN_PREDATOR_PREY = "simple_predator_prey"
+SCN_CONSENSUS = "consensus"
 
 
 @dataclass
@@ -121,6 +122,8 @@ class Spec:
             return [2 + 2 * L + 3 + self.dim_c] * A
         if self.scenario == SCN_CRYPTO:
             return [self.dim_c, 2 * self.dim_c, 2 * self.dim_c]
+        if self.scenario == SCN_CONSENSUS:
+            return [2 * 2 * CONSENSUS_HISTORY * 2] * A      # 2 neighbours x (velocity, position) history x 2 coordinates
         if self.scenario == SCN_PREDATOR_PREY:
             # vel, pos, own holding (members), others' pos and vel, members' holding, landmarks, in_forest
             return [4 + 2 * (A - 1) * 2 + 3 + 2 * L + 2] * A
@@ -252,7 +255,23 @@ def spec_predator_prey() -> Spec:
                 new_core=True, accel=np.full(A, np.nan))
 
 
+CONSENSUS_HISTORY = 10
+
+
+def spec_consensus() -> Spec:
+    """consensus.make_world, multiagent/scenarios/consensus.py:8-44, on the new_core physics: 6 silent,
+    non-colliding ghost agents of size 0.03 in the walled arena (the walls are hard, so they still act
+    on ghosts, new_core.py:302); no landmarks; shared rewards (:24)."""
+    A = 6
+    return Spec(SCN_CONSENSUS, A, 0, 2, np.full(A, 0.03), np.ones(A, bool), np.zeros(A, bool), np.ones(A),
+                sens=np.full(A, 5.0), max_speed=np.full(A, np.inf), silent=np.ones(A, bool), adversary=np.zeros(A, bool),
+                leader=np.zeros(A, bool), walls=[dict(w) for w in ARENA_WALLS], ghost=np.ones(A, bool), shared=True,
+                new_core=True, accel=np.full(A, np.nan))
+
+
 def make_spec(name: str, **kw) -> Spec:
+    if name == SCN_CONSENSUS:
+        return spec_consensus()
     if name == SCN_PREDATOR_PREY:
         return spec_predator_prey()
     if name == SCN_SPEAKER_LISTENER:
@@ -743,14 +762,15 @@ def info(spec: Spec, pos, goal=None, comm=None):
 
 
 def share(spec: Spec, rew):
-    """environment.py:103-105: with World.collaborative every agent receives np.sum(reward_n),
-    which adds the first reward to the running sum of the others."""
+    """environment.py:103-105: with World.collaborative every agent receives np.sum(reward_n); for
+    fewer than 8 values numpy adds them left to right (its pairwise blocking starts at 8)."""
     if not spec.shared:
         return rew
-    rest = np.zeros(rew.shape[0])
+    assert spec.A < 8
+    total = rew[:, 0]
     for i in range(1, spec.A):
-        rest = rest + rew[:, i]
-    return np.repeat((rew[:, 0] + rest)[:, None], spec.A, axis=1)
+        total = total + rew[:, i]
+    return np.repeat(total[:, None], spec.A, axis=1)
 
 
 def env_step(spec: Spec, pos, vel, actions, goal=None):
@@ -1007,3 +1027,50 @@ def pp_device_reset(spec: Spec, seed, episode, B):
             pos[bad, e, :] = device_reset_draw(seed, b[bad], episode, e, 0.9, attempt)
     key = device_aux_words(seed, b, episode)[:, 0].astype(np.int32)
     return pos, key
+
+
+# --------------------------------------------------------------------------
+# consensus (multiagent/scenarios/consensus.py) on the new_core physics.  Beside pos / vel the world
+# carries his_pos / his_vel [B, A, 10, 2]: the last ten positions and velocities of every agent,
+# oldest first (state.p_his_pos / p_his_vel, slid by World.integrate_state, new_core.py:252-254).
+# --------------------------------------------------------------------------
+def consensus_neighbors(A: int, i: int):
+    """neighbors(), consensus.py:79-83: the agents sharing an edge of the ring comm_matrix (:15-22), ascending."""
+    return sorted({(i - 1) % A, (i + 1) % A} - {i})
+
+
+def consensus_observe(spec: Spec, his_pos, his_vel) -> List[np.ndarray]:
+    """observation(), consensus.py:122-140: neighbours' velocity-history offsets, then position-history
+    offsets, flattened; cast to float32."""
+    B = his_pos.shape[0]
+    out = []
+    for i in range(spec.A):
+        nbs = consensus_neighbors(spec.A, i)
+        parts = [his_vel[:, n] - his_vel[:, i] for n in nbs] + [his_pos[:, n] - his_pos[:, i] for n in nbs]
+        out.append(np.concatenate(parts, axis=1).reshape(B, -1).astype(np.float32))
+    return out
+
+
+def consensus_reward(spec: Spec, pos) -> np.ndarray:
+    """reward(), consensus.py:91-113 (before sharing)."""
+    B = pos.shape[0]
+    rew = np.zeros((B, spec.A))
+    for i in range(spec.A):
+        d = [_dist(pos[:, n, :] - pos[:, i, :]) for n in consensus_neighbors(spec.A, i)]
+        r = 0 - (np.abs(d[0] - 0.8) + np.abs(d[1] - 0.8)) * 0.1
+        if i == 0:
+            r = r - np.abs(_dist(pos[:, 0, :]) - 0.8) * 0.1
+        for p in range(2):
+            r = r - 2 * _bound(np.abs(pos[:, i, p]))
+        rew[:, i] = r
+    return rew
+
+
+def consensus_env_step(spec: Spec, pos, vel, his_pos, his_vel, actions):
+    """MultiAgentEnv.step for consensus.  Returns (pos, vel, his_pos, his_vel, obs_list, shared rew, own rew)."""
+    u, c = decode_actions(spec, actions)
+    pos, vel, _ = world_step(spec, pos, vel, u, c)
+    his_pos = np.concatenate([his_pos[:, :, 1:], pos[:, :spec.A, None, :]], axis=2)
+    his_vel = np.concatenate([his_vel[:, :, 1:], vel[:, :, None, :]], axis=2)
+    own = consensus_reward(spec, pos)
+    return pos, vel, his_pos, his_vel, consensus_observe(spec, his_pos, his_vel), share(spec, own), own

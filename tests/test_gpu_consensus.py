@@ -1,0 +1,128 @@
+"""consensus (new_core physics, walls, 10-step history observations, reward shared over six agents)
+on the GPU against the reference fixture and the oracle.  Bars as in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import mpe_oracle as orc
+from conftest import load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+CASE = "consensus"
+
+
+def _close(a, b, rtol, atol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def _env(B, dtype, **kw):
+    import mpe_hip
+    return mpe_hip.BatchedEnv(CASE, B, dtype=dtype, device="cuda:0", **kw)
+
+
+def test_layout_and_refusals():
+    import mpe_hip
+    g = load_golden(CASE)
+    env = _env(8, torch.float64)
+    assert env.obs_dims == list(g["obs_dims"]) and env.n_act == 6 and env.layout.n_hist_rows == 240 and env.layout.n_aux == 1
+    assert tuple(env.comm.shape) == (240, 8)
+    with pytest.raises(mpe_hip.MpeError):
+        e = _env(8, torch.float32, max_episode_steps=5)
+        e.step(torch.zeros(8, 6, dtype=torch.int32))
+    with pytest.raises(ValueError):
+        _env(8, torch.float32, info=True)
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", [("float64", 1e-9, 1e-12), ("float32", 1e-4, 1e-4)])
+def test_trajectory_matches_reference(dtype, rtol, atol):
+    g = load_golden(CASE)
+    T, B, A = g["actions"].shape
+    env = _env(B, getattr(torch, dtype))
+    env.set_state(g["pos0"], g["vel0"])
+    env.set_history(g["his_pos0"], g["his_vel0"])
+    env.observe(score=True)
+    assert _close(env.obs.cpu().numpy(), g["obs0"], rtol, atol)
+    assert _close(env.rew.cpu().numpy(), orc.consensus_reward(orc.make_spec(CASE), g["pos0"]), rtol, atol * 2)
+    for t in range(T):
+        obs, rew, done, _ = env.step(torch.as_tensor(g["actions"][t]))
+        pos, vel, _ = env.get_state()
+        assert _close(pos, g["pos"][t], rtol, atol), (t, np.abs(pos - g["pos"][t]).max())
+        assert _close(vel, g["vel"][t], rtol, atol), t
+        assert _close(obs.cpu().numpy(), g["obs"][t], rtol, atol * 2), (t, np.abs(obs.cpu().numpy() - g["obs"][t]).max())
+        assert _close(rew.cpu().numpy(), g["rew"][t], rtol, atol * 20), t
+        assert not done.any()
+    hp, hv = env.get_history()
+    assert _close(hp, g["pos"][T - 10:].transpose(1, 2, 0, 3), rtol, atol) and _close(hv, g["vel"][T - 10:].transpose(1, 2, 0, 3), rtol, atol)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_rollout_and_episode_equal_stepping(dtype):
+    dt = getattr(torch, dtype)
+    B, T = 1000, 25
+    e1, e2, e3 = _env(B, dt), _env(B, dt), _env(B, dt)
+    a = torch.randint(0, 5, (T, B, 6), dtype=torch.int32, device="cuda:0", generator=torch.Generator("cuda:0").manual_seed(5))
+    e1.reset(seed=11, observe=False)
+    e2.reset(seed=11, observe=False)
+    out2 = e2.rollout(a)
+    out3 = e3.rollout(a, reset_seed=11)
+    for t in range(T):
+        obs, rew, done, _ = e1.step(a[t])
+        assert torch.equal(obs, out2["obs"][t]) and torch.equal(rew, out2["rew"][t]) and torch.equal(done, out2["done"][t]), t
+    for k in ("obs", "rew", "done"):
+        assert torch.equal(out2[k], out3[k]), k
+    for k in ("pos", "vel", "comm", "aux"):
+        assert torch.equal(getattr(e1, k), getattr(e2, k)) and torch.equal(getattr(e1, k), getattr(e3, k)), k
+
+
+def test_large_batch_fp64_against_oracle_with_masked_reset():
+    """Device reset, free-running steps; half of the worlds are reset again mid-way, so the worlds of a
+    wave no longer share their ring head."""
+    spec = orc.make_spec(CASE)
+    B, T = 1500, 24
+    env = _env(B, torch.float64)
+    env.reset(seed=5, observe=False)
+    pos, vel, _ = env.get_state()
+    want = np.stack([orc.device_reset_draw(5, np.arange(B, dtype=np.uint64), 0, i, 1.0) for i in range(6)], axis=1)
+    assert np.array_equal(pos, want) and not vel.any()
+    hp, hv = env.get_history()
+    assert np.array_equal(hp, np.repeat(pos[:, :, None, :], 10, axis=2)) and not hv.any()
+    rng = np.random.RandomState(1)
+    for t in range(T):
+        if t == 7:
+            mask = (np.arange(B) % 2 == 0)
+            env.reset(seed=6, mask=torch.as_tensor(mask.astype(np.uint8)), observe=False)
+            p2, v2, _ = env.get_state()
+            assert np.array_equal(p2[~mask], pos[~mask]) and not np.array_equal(p2[mask], pos[mask])
+            pos[mask], vel[mask] = p2[mask], 0.0
+            hp[mask], hv[mask] = np.repeat(p2[mask][:, :, None, :], 10, axis=2), 0.0
+        a = rng.randint(0, 5, (B, 6))
+        obs, rew, done, _ = env.step(torch.as_tensor(a))
+        pos, vel, hp, hv, o_obs, o_rew, _ = orc.consensus_env_step(spec, pos, vel, hp, hv, a)
+        gp, gv, _ = env.get_state()
+        assert _close(gp, pos, 1e-9, 1e-12) and _close(gv, vel, 1e-9, 1e-12), t
+        assert _close(obs.cpu().numpy(), np.concatenate(o_obs, axis=1), 1e-9, 1e-12), t
+        assert _close(rew.cpu().numpy(), o_rew, 1e-9, 1e-12), t
+    ghp, ghv = env.get_history()
+    assert _close(ghp, hp, 1e-9, 1e-12) and _close(ghv, hv, 1e-9, 1e-12)
+    assert len(set(env.aux[0].cpu().numpy().tolist())) == 2
+
+
+def test_drop_in_env_replays_the_reference():
+    import mpe_hip
+    g = load_golden(CASE)
+    env = mpe_hip.make_env(CASE, benchmark=True)
+    assert env.shared_reward and env.n == 6
+    env.seed(0)
+    env.reset()
+    b = 20
+    for i, a in enumerate(env.world.agents):
+        a.state.p_pos, a.state.p_vel = g["pos0"][b, i].copy(), g["vel0"][b, i].copy()
+        a.state.p_his_pos, a.state.p_his_vel = g["his_pos0"][b, i].copy(), g["his_vel0"][b, i].copy()
+    assert _close(np.concatenate([env._get_obs(a) for a in env.agents]), g["obs0"][b], 1e-9, 1e-12)
+    for t in range(25):
+        obs_n, rew_n, done, info = env.step([int(x) for x in g["actions"][t, b]])
+        assert obs_n[0].dtype == np.float32 and _close(np.concatenate(obs_n), g["obs"][t, b], 1e-9, 1e-12), t
+        assert _close(rew_n, g["rew"][t, b], 1e-9, 1e-12) and done is False
+        assert _close([info["r%d" % i] for i in range(6)], g["rew_own"][t, b], 1e-9, 1e-12)
+        assert info["n"] == [(0, 0, 0, 0)] * 6

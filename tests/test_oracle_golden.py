@@ -235,3 +235,18 @@ def test_philox_known_answers():
     assert [hex(x) for x in orc.philox4x32(full, full, full)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
     pi = orc.philox4x32(np.uint64(0x299F31D0A4093822), np.uint64(0x85A308D3243F6A88), np.uint64(0x0370734413198A2E))
     assert [hex(x) for x in pi] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_oracle_reproduces_consensus():
+    """consensus through the reference's MultiAgentEnv.step: state, history observations, shared
+    (np.sum over six agents) and own rewards bit for bit."""
+    g = load_golden("consensus")
+    spec = orc.make_spec("consensus")
+    assert spec.obs_dims == list(g["obs_dims"]) and spec.n_act == 6
+    pos, vel, hp, hv = g["pos0"].copy(), g["vel0"].copy(), g["his_pos0"].copy(), g["his_vel0"].copy()
+    assert np.array_equal(np.concatenate(orc.consensus_observe(spec, hp, hv), axis=1), g["obs0"])
+    for t in range(g["actions"].shape[0]):
+        pos, vel, hp, hv, obs, rew, own = orc.consensus_env_step(spec, pos, vel, hp, hv, g["actions"][t])
+        assert np.array_equal(pos, g["pos"][t]) and np.array_equal(vel, g["vel"][t]), t
+        assert np.array_equal(np.concatenate(obs, axis=1), g["obs"][t]), t
+        assert np.array_equal(own, g["rew_own"][t]) and np.array_equal(rew, g["rew"][t]), t

@@ -129,7 +129,7 @@ def load_reference():
     ref.environment = _load("multiagent.environment", os.path.join(REF, "multiagent", "environment.py"))
     ref.scenarios = {}
     for n in ("simple_spread", "simple_tag", "simple_world_comm", "simple", "simple_adversary", "simple_push",
-              "simple_speaker_listener", "simple_reference", "simple_crypto", "simple_predator_prey"):
+              "simple_speaker_listener", "simple_reference", "simple_crypto", "simple_predator_prey", "consensus"):
         ref.scenarios[n] = _load("ref_scn_" + n, os.path.join(REF, "multiagent", "scenarios", n + ".py"))
     return ref
 
@@ -781,6 +781,59 @@ def run_predator_prey(ref, seed=20240641, B=32):
     return pos0, vel0, actions, rec
 
 
+def run_consensus(ref, seed=20240651, B=32):
+    """consensus through MultiAgentEnv.step (new_core physics, walls, 10-step history observations,
+    shared reward over 6 agents)."""
+    sc = ref.scenarios["consensus"].Scenario()
+    world = sc.make_world()
+    env = ref.environment.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data)
+    A = len(world.agents)
+    assert A == 6 and len(world.landmarks) == 0 and env.shared_reward
+    rng = np.random.RandomState(seed)
+    pos0 = rng.uniform(-1, 1, (B, A, 2))
+    vel0 = np.zeros((B, A, 2))
+    vel0[B // 2:] = rng.uniform(-1, 1, (B - B // 2, A, 2))
+    # agents at / beyond the arena edge (bound() branches, wall contact) and on the target circle
+    for k, b in enumerate(range(8)):
+        x = [0.85, 0.8999, 0.95, 0.9999, 1.0, 1.05, 1.3, 0.97][k]
+        pos0[b, k % A] = (x if k % 2 == 0 else -x, 0.99 * (-1) ** k)
+    pos0[8, 0] = (0.8, 0.0)
+    pos0[9, 0] = (0.0, 0.0)
+    # histories: a fresh episode (all rows equal the start, consensus.py:56-58) or a recorded past
+    his_pos0 = np.repeat(pos0[:, :, None, :], 10, axis=2)
+    his_vel0 = np.repeat(vel0[:, :, None, :], 10, axis=2)
+    past = slice(B // 4, B)
+    his_pos0[past, :, :9] += rng.uniform(-0.3, 0.3, (B - B // 4, A, 9, 2))
+    his_vel0[past, :, :9] = rng.uniform(-1, 1, (B - B // 4, A, 9, 2))
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+    for k in range(4):
+        actions[:, k, k % A] = [2, 1, 2, 1][k]           # keep pushing into the wall
+    dims = [sp.shape[0] for sp in env.observation_space]
+    rec = {"pos": np.zeros((T_STEPS, B, A, 2)), "vel": np.zeros((T_STEPS, B, A, 2)),
+           "obs": np.zeros((T_STEPS, B, sum(dims)), np.float32), "obs_dims": np.array(dims, np.int64),
+           "rew": np.zeros((T_STEPS, B, A)), "rew_own": np.zeros((T_STEPS, B, A)), "done": np.zeros((T_STEPS, B), np.uint8),
+           "obs0": np.zeros((B, sum(dims)), np.float32), "his_pos0": his_pos0, "his_vel0": his_vel0}
+    env.seed(0)
+    for b in range(B):
+        env.reset()
+        inject(world, pos0[b], vel0[b])
+        for i, a in enumerate(world.agents):
+            a.state.p_his_pos = his_pos0[b, i].copy()
+            a.state.p_his_vel = his_vel0[b, i].copy()
+        rec["obs0"][b] = np.concatenate([sc.observation(a, world) for a in world.agents])
+        for t in range(T_STEPS):
+            obs_n, rew_n, done, info_n = env.step([int(a) for a in actions[t, b]])
+            for i, ag in enumerate(world.agents):
+                rec["pos"][t, b, i] = ag.state.p_pos
+                rec["vel"][t, b, i] = ag.state.p_vel
+            rec["obs"][t, b] = np.concatenate(obs_n)
+            rec["rew"][t, b] = [float(r) for r in rew_n]
+            rec["rew_own"][t, b] = [float(info_n["r%d" % i]) for i in range(A)]
+            rec["done"][t, b] = bool(done)
+            assert all(x == (0, 0, 0, 0) for x in info_n["n"])          # no landmarks, agents do not collide
+    return pos0, vel0, actions, rec
+
+
 def known_answers(ref):
     """Anchors that do not use state injection."""
     out = {}
@@ -864,6 +917,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "simple_predator_prey.npz"), scenario=np.array("simple_predator_prey"), pos0=pos0, vel0=vel0,
                         actions=actions.astype(np.int32), **rec)
     print("wrote simple_predator_prey.npz")
+
+    pos0, vel0, actions, rec = run_consensus(ref)
+    np.savez_compressed(os.path.join(OUT, "consensus.npz"), scenario=np.array("consensus"), pos0=pos0, vel0=vel0,
+                        actions=actions.astype(np.int32), **rec)
+    print("wrote consensus.npz")
 
     for key, (scn, kw, pos0, vel0, actions, rec) in cases.items():
         path = os.path.join(OUT, key + ".npz")

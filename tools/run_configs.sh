@@ -24,3 +24,4 @@ run speaker_listener_B262144 --scenario simple_speaker_listener --envs 262144 --
 run reference_B262144 --scenario simple_reference --envs 262144 --steps 1000 --warmup 100
 run crypto_B262144 --scenario simple_crypto --envs 262144 --steps 1000 --warmup 100
 run predator_prey_B131072 --scenario simple_predator_prey --envs 131072 --steps 500 --warmup 50
+run consensus_B65536 --scenario consensus --envs 65536 --steps 500 --warmup 50
