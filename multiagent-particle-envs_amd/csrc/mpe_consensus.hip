@@ -10,7 +10,8 @@
 // Rows are env-minor, so as long as the worlds of a wave share their head (they do unless they were
 // reset at different times) every history access is a coalesced 256-byte row.
 //
-// The observation of a world-step is 6 x 80 values; it is produced one agent at a time into an
+// The observation of a world-step is 6 x 80 values; it is produced one agent at a time (a window of
+// three agents' histories in registers slides round the ring) into an
 // LDS tile of 64 x 80 (row stride 81: conflict-free row writes) and streamed to the env-major
 // output 4 bytes per lane, i.e. contiguous 256-byte runs.  Rewards leave through a small tile too.
 #include "mpe_launch.hpp"
@@ -145,30 +146,55 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
         }
 
         // ---- observation(), consensus.py:122-140, one agent at a time ----
-        for (int i = 0; i < CA; ++i) {
-            const int n0 = nb_lo(i), n1 = nb_hi(i);
-            T* orow = tile_obs + lane * CSTRIDE;
-            for (int k = 0; k < CH; ++k) {
-                int slot = head + k;
-                slot = slot >= CH ? slot - CH : slot;
-                T me[4], lo[4], hi[4];
+        // Agent i needs the histories of i - 1, i, i + 1: walking the ring in order, each step of the walk
+        // loads one more agent's 40 values and drops one (agent 5's stay for the end, agent 0's are
+        // fetched again for agent 5), 7 agent histories per world-step instead of 18.
+        {
+            T H[CA][4 * CH];
+            auto load_agent = [&](int j) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { me[c] = hist_g[hrow(slot, i, c)]; lo[c] = hist_g[hrow(slot, n0, c)]; hi[c] = hist_g[hrow(slot, n1, c)]; }
-                // [lo vel history (20), hi vel history (20), lo pos history (20), hi pos history (20)]
-                orow[2 * k] = f32r(lo[2] - me[2]); orow[2 * k + 1] = f32r(lo[3] - me[3]);
-                orow[2 * CH + 2 * k] = f32r(hi[2] - me[2]); orow[2 * CH + 2 * k + 1] = f32r(hi[3] - me[3]);
-                orow[4 * CH + 2 * k] = f32r(lo[0] - me[0]); orow[4 * CH + 2 * k + 1] = f32r(lo[1] - me[1]);
-                orow[6 * CH + 2 * k] = f32r(hi[0] - me[0]); orow[6 * CH + 2 * k + 1] = f32r(hi[1] - me[1]);
+                for (int k = 0; k < CH; ++k) {
+                    int slot = head + k;
+                    slot = slot >= CH ? slot - CH : slot;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) H[j][4 * k + c] = hist_g[hrow(slot, j, c)];
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < CA; ++i) {
+                if (i == 0) { load_agent(CA - 1); load_agent(0); load_agent(1); }
+                else if (i + 1 < CA - 1) load_agent(i + 1);
+                else if (i == CA - 1) load_agent(0);
+                const int n0 = nb_lo(i), n1 = nb_hi(i);
+                T* orow = tile_obs + lane * CSTRIDE;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const T* me = &H[i][4 * k];
+                    const T* lo = &H[n0][4 * k];
+                    const T* hi = &H[n1][4 * k];
+                    // [lo vel history (20), hi vel history (20), lo pos history (20), hi pos history (20)]
+                    orow[2 * k] = f32r(lo[2] - me[2]); orow[2 * k + 1] = f32r(lo[3] - me[3]);
+                    orow[2 * CH + 2 * k] = f32r(hi[2] - me[2]); orow[2 * CH + 2 * k + 1] = f32r(hi[3] - me[3]);
+                    orow[4 * CH + 2 * k] = f32r(lo[0] - me[0]); orow[4 * CH + 2 * k + 1] = f32r(lo[1] - me[1]);
+                    orow[6 * CH + 2 * k] = f32r(hi[0] - me[0]); orow[6 * CH + 2 * k + 1] = f32r(hi[1] - me[1]);
+                }
+                __syncthreads();
+                // stream the 64 x 80 tile out as 16-byte vectors (an agent's 80 values start on a 16-byte boundary
+                // of the row for both float types): vector g covers values [VEC * g, VEC * g + VEC) of row g / NVR
+                constexpr int VEC = 16 / (int)sizeof(T), NVR = COBS / VEC;
+                typedef T VT __attribute__((ext_vector_type(VEC)));
+                T* gbase = obs_g + row * (CA * COBS) + i * COBS;
+#pragma unroll 4
+                for (int it = 0; it < NVR; ++it) {          // 64 * NVR vectors, 64 per iteration
+                    const int g = it * 64 + lane;
+                    const int r = g / NVR, j = (g - r * NVR) * VEC;
+                    VT v;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[q] = tile_obs[r * CSTRIDE + j + q];
+                    if (r < nvalid) *reinterpret_cast<VT*>(gbase + (long long)r * (CA * COBS) + j) = v;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            const int n = nvalid * COBS;
-            T* gbase = obs_g + row * (CA * COBS) + i * COBS;
-            for (int it = 0; it < COBS; ++it) {         // 64 * COBS values, 64 per iteration
-                const int g = it * 64 + lane;
-                const int r = g / COBS;
-                if (g < n) gbase[(long long)r * (CA * COBS) + (g - r * COBS)] = tile_obs[r * CSTRIDE + (g - r * COBS)];
-            }
-            __syncthreads();
         }
         if (MODE != 2 || rew_g != nullptr) {
             const int n = nvalid * CA;
