@@ -122,6 +122,9 @@ class Spec:
             return [2 + 2 * L + 3 + self.dim_c] * A
         if self.scenario == SCN_CRYPTO:
             return [self.dim_c, 2 * self.dim_c, 2 * self.dim_c]
+        if self.scenario == "collector":
+            # pos, vel, own holding (collectors), 7 other agents x (offset, vel, encoding), 6 treasures x (offset, type)
+            return [4 + (2 if i < 6 else 0) + 7 * 8 + 6 * 4 for i in range(A)]
         if self.scenario == SCN_CONSENSUS:
             return [2 * 2 * CONSENSUS_HISTORY * 2] * A      # 2 neighbours x (velocity, position) history x 2 coordinates
         if self.scenario == SCN_PREDATOR_PREY:
@@ -270,6 +273,8 @@ def spec_consensus() -> Spec:
 
 
 def make_spec(name: str, **kw) -> Spec:
+    if name == "collector":
+        return spec_collector()
     if name == SCN_CONSENSUS:
         return spec_consensus()
     if name == SCN_PREDATOR_PREY:
@@ -1074,3 +1079,160 @@ def consensus_env_step(spec: Spec, pos, vel, his_pos, his_vel, actions):
     his_vel = np.concatenate([his_vel[:, :, 1:], vel[:, :, None, :]], axis=2)
     own = consensus_reward(spec, pos)
     return pos, vel, his_pos, his_vel, consensus_observe(spec, his_pos, his_vel), share(spec, own), own
+
+
+# --------------------------------------------------------------------------
+# collector (multiagent/scenarios/collector.py) on the new_core physics: collectors 0-5 pick up
+# treasures of two types and carry them to the deposit of that type (agents 6, 7).  Beside pos / vel
+# the world carries holding [B, 6] (-1: nothing, else the type), ttype [B, 6] and alive [B, 6] of the
+# treasures.  The callbacks are restated per world in scalar form, following the reference's own
+# loops (data-dependent sorting and branching); distances are those of the cache World.step fills.
+# --------------------------------------------------------------------------
+SCN_COLLECTOR = "collector"
+COL_N_COLLECTORS = 6
+
+
+def spec_collector() -> Spec:
+    """collector.make_world, collector.py:8-71: 6 collectors (size .05, mass 1) and 2 deposits (size
+    .075, mass 2.25), all colliding ghosts with accel 1.5 and max_speed 1; 6 treasures (size .025) that
+    neither collide nor move; no walls (num_walls = 0)."""
+    A, L = 8, 6
+    col = np.arange(A) < COL_N_COLLECTORS
+    return Spec(SCN_COLLECTOR, A, L, 2, np.concatenate([np.where(col, 0.05, 0.075), np.full(L, 0.025)]),
+                np.array([True] * A + [False] * L), np.array([True] * A + [False] * L), np.concatenate([np.where(col, 1.0, 2.25), np.ones(L)]),
+                sens=np.full(A, 1.5), max_speed=np.ones(A), silent=np.ones(A, bool), adversary=np.zeros(A, bool), leader=np.zeros(A, bool),
+                ghost=np.ones(A, bool), new_core=True, accel=np.full(A, 1.5))
+
+
+def _col_cache(spec, pos1):
+    """cached_dist_vect / cached_dist_mag of one world (new_core.py:147-170): vect[a, b] = p_a - p_b."""
+    vect = pos1[:, None, :] - pos1[None, :, :]
+    mag = np.sqrt(vect[..., 0] * vect[..., 0] + vect[..., 1] * vect[..., 1])
+    return vect, mag
+
+
+def _col_hit(spec, mag, a, b):
+    return bool(mag[a, b] < spec.size[a] + spec.size[b])
+
+
+def collector_observe1(spec, pos1, vel1, holding1, ttype1):
+    """observation() of every agent of one world, collector.py:257-295 (cast to float32)."""
+    A, L, NC = spec.A, spec.L, COL_N_COLLECTORS
+    vect, mag = _col_cache(spec, pos1)
+    onehot = lambda v: (np.arange(2) == v)
+
+    def encoding(j):
+        return np.concatenate([np.zeros(2), onehot(holding1[j])]) if j < NC else np.concatenate([onehot(j - NC), np.zeros(2)])
+
+    out = []
+    for i in range(A):
+        others = [j for j in range(A) if j != i]
+        closest = sorted(zip(mag[others, i], others))
+        treasures = list(range(A, A + L))
+        closest_t = sorted(zip(mag[treasures, i], treasures))
+        obs = [pos1[i], vel1[i]]
+        if i < NC:
+            obs.append(onehot(holding1[i]))
+        for _, j in closest:
+            obs += [vect[j, i], vel1[j], encoding(j)]
+        for _, t in closest_t:
+            obs += [vect[t, i], onehot(ttype1[t - A])]
+        out.append(np.concatenate(obs).astype(np.float32))
+    return out
+
+
+def collector_reward1(spec, pos1, holding1, alive1):
+    """reward() of every agent of one world, collector.py:165-255: everything goes to collector 0."""
+    A, L, NC = spec.A, spec.L, COL_N_COLLECTORS
+    vect, mag = _col_cache(spec, pos1)
+    collectors, deposits, treasures = list(range(NC)), list(range(NC, A)), list(range(A, A + L))
+    gdr = 0
+    for d in deposits:                                                    # :248-255
+        gdr += 5 * sum(_col_hit(spec, mag, d, a) for a in collectors if holding1[a] == d - NC)
+    gcr = 0
+    for t in treasures:                                                   # :239-246
+        if alive1[t - A]:
+            gcr += 5 * sum(_col_hit(spec, mag, a, t) for a in collectors if holding1[a] < 0)
+    glob = gdr + gcr
+
+    def deposit_reward(d):                                                # :177-213
+        rew = 0
+        dh = [mag[d, a] for a in collectors if holding1[a] == d - NC]
+        if len(dh) > 0:
+            rew -= 0.1 * min(dh)
+        else:
+            closest = sorted(zip(mag[collectors, d], collectors))[:A - 1]
+            inds = [i for _, i in closest]
+            rew -= 0.1 * np.linalg.norm(vect[inds, d].mean(axis=0))
+        rew += gdr
+        for a in collectors:
+            if holding1[a] < 0:
+                rew -= 0.1 * min([mag[t, a] for t in treasures if alive1[t - A]])
+            else:
+                rew -= 0.1 * min([mag[a, dd] for dd in deposits if dd - NC == holding1[a]])
+            rew += glob
+        return rew
+
+    def collector_reward(a):                                              # :215-229
+        return 0 - 5 * sum(_col_hit(spec, mag, a, o) for o in collectors if o != a)
+
+    main = 0.0
+    main += sum([deposit_reward(d) for d in deposits])
+    main += sum([collector_reward(a) for a in collectors])
+    return np.array([main] + [0.0] * (A - 1))
+
+
+def collector_info1(spec, pos1, holding1):
+    """benchmark_data() of every agent of one world, collector.py:132-155: (collected, deposited, collisions)."""
+    A, L, NC = spec.A, spec.L, COL_N_COLLECTORS
+    _, mag = _col_cache(spec, pos1)
+    out = np.zeros((A, 3), np.int64)
+    for i in range(A):
+        if i < NC:
+            if holding1[i] < 0:
+                out[i, 0] = sum(_col_hit(spec, mag, t, i) for t in range(A, A + L))
+            out[i, 2] = sum(_col_hit(spec, mag, a, i) for a in range(NC) if a != i)
+        else:
+            out[i, 1] = sum(_col_hit(spec, mag, a, i) for a in range(NC) if holding1[a] == i - NC)
+    return out
+
+
+def collector_post_step1(spec, pos1, holding1, ttype1, alive1, respawn_pos1, respawn_type1):
+    """post_step(), collector.py:84-110, on one world (arrays are modified in place): a live treasure is
+    taken by the first empty-handed collector touching it and parked at the origin; a dead one respawns
+    (respawn_prob 1) at respawn_pos1 with respawn_type1; a collector touching the deposit of the type it
+    holds hands over.  Distances are those cached before any treasure moved."""
+    A, L, NC = spec.A, spec.L, COL_N_COLLECTORS
+    _, mag = _col_cache(spec, pos1)
+    for l in range(L):
+        if alive1[l]:
+            for a in range(NC):
+                if holding1[a] < 0 and _col_hit(spec, mag, A + l, a):
+                    alive1[l] = False
+                    holding1[a] = ttype1[l]
+                    pos1[A + l] = (-0.0, -0.0)
+                    break
+        else:
+            pos1[A + l] = respawn_pos1[l]
+            ttype1[l] = respawn_type1[l]
+            alive1[l] = True
+    for a in range(NC):
+        if holding1[a] >= 0:
+            for d in range(NC, A):
+                if d - NC == holding1[a] and _col_hit(spec, mag, a, d):
+                    holding1[a] = -1
+
+
+def collector_env_step(spec: Spec, pos, vel, actions, holding, ttype, alive, respawn_pos, respawn_type):
+    """MultiAgentEnv.step with post_step as post_step_callback, for B worlds.  Returns
+    (pos, vel, obs [B, 684] float32, rew [B, A], info [B, A, 3], holding, ttype, alive)."""
+    u, c = decode_actions(spec, actions)
+    pos, vel, _ = world_step(spec, pos, vel, u, c)
+    pos, holding, ttype, alive = pos.copy(), holding.copy(), ttype.copy(), alive.copy()
+    B = pos.shape[0]
+    obs = np.stack([np.concatenate(collector_observe1(spec, pos[b], vel[b], holding[b], ttype[b])) for b in range(B)])
+    rew = np.stack([collector_reward1(spec, pos[b], holding[b], alive[b]) for b in range(B)])
+    info = np.stack([collector_info1(spec, pos[b], holding[b]) for b in range(B)])
+    for b in range(B):
+        collector_post_step1(spec, pos[b], holding[b], ttype[b], alive[b], respawn_pos[b], respawn_type[b])
+    return pos, vel, obs, rew, info, holding, ttype, alive

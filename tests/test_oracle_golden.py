@@ -250,3 +250,29 @@ def test_oracle_reproduces_consensus():
         assert np.array_equal(pos, g["pos"][t]) and np.array_equal(vel, g["vel"][t]), t
         assert np.array_equal(np.concatenate(obs, axis=1), g["obs"][t]), t
         assert np.array_equal(own, g["rew_own"][t]) and np.array_equal(rew, g["rew"][t]), t
+
+
+def test_oracle_reproduces_collector():
+    """collector through the reference's MultiAgentEnv.step (post_step as post_step_callback), free-running
+    for 25 steps with the respawn positions and types the reference drew fed back in: state, sorted-nearest
+    observations, the reward (all of it goes to collector 0), benchmark_data and the pick-up / hand-over
+    state bit for bit."""
+    g = load_golden("collector")
+    spec = orc.make_spec("collector")
+    A = spec.A
+    assert spec.obs_dims == list(g["obs_dims"])
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    holding, ttype, alive = g["holding0"].copy(), g["ttype0"].copy(), g["alive0"].copy()
+    B = pos.shape[0]
+    obs0 = np.stack([np.concatenate(orc.collector_observe1(spec, pos[b], vel[b], holding[b], ttype[b])) for b in range(B)])
+    assert np.array_equal(obs0, g["obs0"])
+    for t in range(g["actions"].shape[0]):
+        pos, vel, obs, rew, info, holding, ttype, alive = orc.collector_env_step(spec, pos, vel, g["actions"][t], holding, ttype, alive,
+                                                                                 g["treasure_pos"][t], g["ttype"][t])
+        assert np.array_equal(pos[:, :A], g["pos"][t]) and np.array_equal(vel, g["vel"][t]), t
+        assert np.array_equal(obs, g["obs"][t]), t
+        assert np.array_equal(rew, g["rew"][t]), (t, np.abs(rew - g["rew"][t]).max())
+        assert np.array_equal(info, g["info"][t]), t
+        assert np.array_equal(holding, g["holding"][t]) and np.array_equal(ttype, g["ttype"][t]) and np.array_equal(alive, g["alive"][t]), t
+        assert np.array_equal(pos[:, A:], g["treasure_pos"][t]), t
+    assert (~g["alive"]).sum() > 5 and (g["holding"] >= 0).sum() > 100 and g["info"][..., 2].sum() > 10

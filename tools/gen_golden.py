@@ -129,7 +129,7 @@ def load_reference():
     ref.environment = _load("multiagent.environment", os.path.join(REF, "multiagent", "environment.py"))
     ref.scenarios = {}
     for n in ("simple_spread", "simple_tag", "simple_world_comm", "simple", "simple_adversary", "simple_push",
-              "simple_speaker_listener", "simple_reference", "simple_crypto", "simple_predator_prey", "consensus"):
+              "simple_speaker_listener", "simple_reference", "simple_crypto", "simple_predator_prey", "consensus", "collector"):
         ref.scenarios[n] = _load("ref_scn_" + n, os.path.join(REF, "multiagent", "scenarios", n + ".py"))
     return ref
 
@@ -834,6 +834,89 @@ def run_consensus(ref, seed=20240651, B=32):
     return pos0, vel0, actions, rec
 
 
+def run_collector(ref, seed=20240661, B=32):
+    """collector through MultiAgentEnv.step with post_step as post_step_callback (new_core physics with
+    mass-ratio contacts, sorted-nearest observations, pick-up / deposit / respawn state machine).  Respawn
+    positions and types come from env.np_random; the fixture records where every treasure went."""
+    sc = ref.scenarios["collector"].Scenario()
+    world = sc.make_world()
+    env = ref.environment.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data,
+                                        post_step_callback=sc.post_step)
+    A, L, NC = len(world.agents), len(world.landmarks), 6
+    assert (A, L) == (8, 6) and not env.shared_reward and not world.walls
+    rng = np.random.RandomState(seed)
+    pos0 = np.concatenate([rng.uniform(-1, 1, (B, A, 2)), rng.uniform(-0.95, 0.95, (B, L, 2))], axis=1)
+    vel0 = np.zeros((B, A, 2))
+    vel0[B // 2:] = rng.uniform(-0.7, 0.7, (B - B // 2, A, 2))
+    holding0 = np.full((B, NC), -1, np.int64)
+    ttype0 = rng.randint(0, 2, (B, L))
+    alive0 = np.ones((B, L), bool)
+    actions = rng.randint(0, 5, (T_STEPS, B, A))
+
+    def near(center, r):
+        ang = rng.uniform(0, 2 * np.pi)
+        return center + r * np.array([np.cos(ang), np.sin(ang)])
+
+    # envs 0..7: a collector on / next to a treasure (pick-up distance 0.075); in 6 and 7 two collectors compete
+    for b in range(8):
+        d = [0.01, 0.04, 0.0749, 0.0751, 0.03, 0.06, 0.02, 0.05][b]
+        pos0[b, b % NC] = near(pos0[b, A + b % L], d)
+        actions[:2, b, b % NC] = 0
+        if b >= 6:
+            pos0[b, (b + 1) % NC] = pos0[b, b % NC] + 0.11 * np.array([np.cos(b), np.sin(b)])
+    # envs 8..11: a collector holding a treasure next to a deposit (hand-over distance 0.125), right or wrong type
+    for k, b in enumerate(range(8, 12)):
+        holding0[b, k] = k % 2
+        pos0[b, k] = near(pos0[b, NC + (k % 2 if k < 3 else 0)], [0.02, 0.1249, 0.1251, 0.05][k])
+    # envs 12..15: treasures already taken (parked at the origin until they respawn); two at once tie in distance
+    for k, b in enumerate(range(12, 16)):
+        for l in ([k], [k, k + 1])[k % 2]:
+            alive0[b, l % L] = False
+            pos0[b, A + l % L] = (-0.0, -0.0)
+        holding0[b, k] = ttype0[b, k % L]
+    # envs 16..19: collectors in contact (0.1), a collector pressed on a heavy deposit (0.125)
+    for k, b in enumerate(range(16, 20)):
+        pos0[b, 1] = near(pos0[b, 0], [0.03, 0.0999, 0.1001, 0.07][k])
+        pos0[b, 2] = near(pos0[b, NC + k % 2], [0.05, 0.12, 0.13, 0.1][k])
+    # envs 20..23: everybody carries something; in 22 and 23 nobody carries type 1
+    for b in range(20, 24):
+        holding0[b] = rng.randint(0, 2, NC) if b < 22 else 0
+    dims = [sp.shape[0] for sp in env.observation_space]
+    rec = {"pos": np.zeros((T_STEPS, B, A, 2)), "vel": np.zeros((T_STEPS, B, A, 2)),
+           "obs": np.zeros((T_STEPS, B, sum(dims)), np.float32), "obs_dims": np.array(dims, np.int64),
+           "rew": np.zeros((T_STEPS, B, A)), "done": np.zeros((T_STEPS, B), np.uint8), "info": np.zeros((T_STEPS, B, A, 3), np.int64),
+           "treasure_pos": np.zeros((T_STEPS, B, L, 2)), "ttype": np.zeros((T_STEPS, B, L), np.int64), "alive": np.zeros((T_STEPS, B, L), bool),
+           "holding": np.zeros((T_STEPS, B, NC), np.int64), "obs0": np.zeros((B, sum(dims)), np.float32)}
+    env.seed(seed)
+    for b in range(B):
+        env.reset()
+        inject(world, pos0[b], vel0[b])
+        for l, lm in enumerate(world.landmarks):
+            lm.alive, lm.type = bool(alive0[b, l]), int(ttype0[b, l])
+        for k, a in enumerate(world.agents[:NC]):
+            a.holding = None if holding0[b, k] < 0 else int(holding0[b, k])
+        world.calculate_distances()
+        sc.reset_cached_rewards()
+        rec["obs0"][b] = np.concatenate([sc.observation(a, world) for a in world.agents])
+        for t in range(T_STEPS):
+            obs_n, rew_n, done, info_n = env.step([int(a) for a in actions[t, b]])
+            for i, ag in enumerate(world.agents):
+                rec["pos"][t, b, i] = ag.state.p_pos
+                rec["vel"][t, b, i] = ag.state.p_vel
+            rec["obs"][t, b] = np.concatenate(obs_n)
+            rec["rew"][t, b] = [float(r) for r in rew_n]
+            rec["done"][t, b] = bool(done)
+            rec["info"][t, b] = info_n["n"]
+            rec["treasure_pos"][t, b] = [lm.state.p_pos for lm in world.landmarks]
+            rec["ttype"][t, b] = [lm.type for lm in world.landmarks]
+            rec["alive"][t, b] = [lm.alive for lm in world.landmarks]
+            rec["holding"][t, b] = [-1 if a.holding is None else a.holding for a in world.agents[:NC]]
+    rec.update(holding0=holding0, ttype0=ttype0, alive0=alive0)
+    print("collector: pick-ups", int((~rec["alive"]).sum()), "holding steps", int((rec["holding"] >= 0).sum()),
+          "hand-overs", int(((rec["holding"][:-1] >= 0) & (rec["holding"][1:] < 0)).sum()), "collisions", int(rec["info"][..., 2].sum()))
+    return pos0, vel0, actions, rec
+
+
 def known_answers(ref):
     """Anchors that do not use state injection."""
     out = {}
@@ -917,6 +1000,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "simple_predator_prey.npz"), scenario=np.array("simple_predator_prey"), pos0=pos0, vel0=vel0,
                         actions=actions.astype(np.int32), **rec)
     print("wrote simple_predator_prey.npz")
+
+    pos0, vel0, actions, rec = run_collector(ref)
+    np.savez_compressed(os.path.join(OUT, "collector.npz"), scenario=np.array("collector"), pos0=pos0, vel0=vel0,
+                        actions=actions.astype(np.int32), **rec)
+    print("wrote collector.npz")
 
     pos0, vel0, actions, rec = run_consensus(ref)
     np.savez_compressed(os.path.join(OUT, "consensus.npz"), scenario=np.array("consensus"), pos0=pos0, vel0=vel0,
