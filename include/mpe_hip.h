@@ -36,7 +36,9 @@
  *                            simple_predator_prey keeps the state its post_step rewrites every step
  *                            here: row 0 = flags (bit f: food f is alive; bit 3+k: member k, agent 4+k,
  *                            holds food), rows 1 and 2 = key and position of the world's respawn
- *                            stream (set by reset; any values give a valid stream)
+ *                            stream (set by reset; any values give a valid stream).  collector likewise:
+ *                            row 0 = bits 2a, 2a+1: what collector a holds (0 nothing, 1 + treasure type),
+ *                            bit 12+l: type of treasure l, bit 18+l: treasure l is alive; rows 1-2 the stream
  *     Small worlds (one lane simulates one world) keep this env-minor layout so that a wave's 64
  *     worlds load as coalesced rows.  Worlds simulated by a whole wave (MpeLayout.state_env_major
  *     == 1: simple_spread other than 3/3, and MPE_SCN_NONE) store the state arrays transposed,
@@ -85,12 +87,14 @@ extern "C" {
 #define MPE_SCN_CRYPTO 9     /* multiagent/scenarios/simple_crypto.py */
 #define MPE_SCN_PREDATOR_PREY 10 /* multiagent/scenarios/simple_predator_prey.py (on multiagent/new_core.py) */
 #define MPE_SCN_CONSENSUS 11 /* multiagent/scenarios/consensus.py (on multiagent/new_core.py) */
+#define MPE_SCN_COLLECTOR 12 /* multiagent/scenarios/collector.py (on multiagent/new_core.py) */
 
 /* World.step variants (MpeSpec.physics) */
 #define MPE_PHYSICS_CORE 0     /* multiagent/core.py:142-233 */
 #define MPE_PHYSICS_NEW_CORE 1 /* multiagent/new_core.py:188-298: action force scaled by mass (* accel) (:214),
                                   contact between two movable entities split by their mass ratio (:290-294);
-                                  MPE_SCN_NONE (mpe_world_step), MPE_SCN_PREDATOR_PREY, MPE_SCN_CONSENSUS */
+                                  MPE_SCN_NONE (mpe_world_step), MPE_SCN_PREDATOR_PREY, MPE_SCN_CONSENSUS,
+                                  MPE_SCN_COLLECTOR */
 
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_LANDMARKS 64
@@ -154,6 +158,8 @@ typedef struct MpeLayout {
                             simple_speaker_listener, simple_reference, simple_crypto: the aux rows;
                             simple_predator_prey: A collision counts (adversary with good agents) + the
                             flags of aux row 0 as the callbacks saw them (before post_step);
+                            collector: benchmark_data (collector.py:132-155) per agent: treasures touched,
+                            treasures being deposited, collisions with collectors; then aux row 0 likewise;
                             simple, simple_push: none (no benchmark_data), info_i must be NULL */
     int32_t n_info_f;    /* simple_spread: min_dists + A benchmark rewards;
                             simple_adversary: benchmark_data (simple_adversary.py:56-65) flattened in
@@ -188,7 +194,8 @@ const char* mpe_last_error(const MpeHandle* h);
  *   get_collision_force :215-233, integrate_state :193-204, update_agent_state :206-212) ->
  *   the scenario's observation / reward / benchmark_data callbacks.
  * pos, vel and comm are updated in place; aux is read (mpe_step_auto rewrites it when it resets).
- * simple_predator_prey also runs the scenario's post_step (simple_predator_prey.py:83-107) as
+ * simple_predator_prey and collector also run the scenario's post_step (simple_predator_prey.py:83-107,
+ * collector.py:84-110; a taken treasure of collector parks at the origin, a respawn also draws its type) as
  * post_step_callback, after the callbacks (environment.py:107-108): it rewrites aux and moves the food
  * landmarks (pick-up parks a food at -999; a dead food respawns at U(-0.95,0.95)^2 from the world's
  * counter-based stream, where the reference draws from numpy's global generator).
@@ -246,8 +253,9 @@ int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm
  * Scenario.reset_world (simple_spread.py:40-56, simple_tag.py:39-54, simple_world_comm.py:88-113)
  * for every env whose mask byte is non-zero (all envs when mask is NULL): agent positions
  * U(-1,1)^2, landmark positions U(-0.9,0.9)^2 (simple_tag, simple_world_comm, simple_predator_prey,
- * whose foods are redrawn until they touch neither the barrier nor a forest, :139-144) or U(-1,1)^2
- * (all others), zero velocity and comm; the aux landmark indices (goal of simple_adversary.py:41-45,
+ * whose foods are redrawn until they touch neither the barrier nor a forest, :139-144), U(-0.95,0.95)^2
+ * (collector, with a uniform type per treasure, collector.py:122-129) or U(-1,1)^2 (all others), zero
+ * velocity and comm; the aux landmark indices (goal of simple_adversary.py:41-45,
  * simple_push.py:40-42, simple_speaker_listener.py:40; both goal_b of simple_reference.py:33-35; goal
  * and key of simple_crypto.py:61-63) uniform over the landmarks.
  * Draws come from a counter-based generator keyed by (seed, env index, episode); they follow the

@@ -74,6 +74,21 @@ static const char* check_structure(const HostSpec& s) {
                     return "consensus agents share size, mass, accel and ghost and have no speed limit";
             }
             return nullptr;
+        case MPE_SCN_COLLECTOR:
+            if (A != 8 || L != 6 || s.n_walls != 0) return "collector has 8 agents, 6 treasures and no walls";
+            for (int i = 0; i < A; ++i)
+                if (!s.collide[i] || !s.silent[i]) return "collector agents collide and are silent";
+            for (int l = 0; l < L; ++l)
+                if (s.collide[A + l]) return "collector treasures do not collide";
+            {   // the kernel reads one set of magnitudes per role
+                const int rep[14] = {0, 0, 0, 0, 0, 0, 6, 6, 8, 8, 8, 8, 8, 8};
+                for (int e = 0; e < A + L; ++e)
+                    if (s.size[e] != s.size[rep[e]] || s.mass[e] != s.mass[rep[e]]) return "collector: size and mass must be uniform per role";
+                for (int i = 0; i < A; ++i)
+                    if (s.sens[i] != s.sens[rep[i]] || s.max_speed[i] != s.max_speed[rep[i]] || s.force_scale[i] != s.force_scale[rep[i]])
+                        return "collector: accel and max_speed must be uniform per role";
+            }
+            return nullptr;
         case MPE_SCN_PREDATOR_PREY:
             if (A != 7 || L != 6 || s.n_walls != 4) return "simple_predator_prey has 7 agents, 6 landmarks and 4 walls";
             for (int i = 0; i < A; ++i)
@@ -172,6 +187,7 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
             case MPE_SCN_CRYPTO: d = (i == 0) ? s.dim_c : 2 * s.dim_c; break;
             case MPE_SCN_PREDATOR_PREY: d = 4 + 4 * (A - 1) + 3 + 2 * L + 2; break;
             case MPE_SCN_CONSENSUS: d = 2 * 2 * 10 * 2; break;
+            case MPE_SCN_COLLECTOR: d = 4 + (i < 6 ? 2 : 0) + (A - 1) * 8 + L * 4; break;
             default: d = 0;
         }
         lo->obs_dim[i] = d;
@@ -188,6 +204,7 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
         case MPE_SCN_REFERENCE: lo->n_info_i = 2; lo->n_info_f = A; break;
         case MPE_SCN_CRYPTO: lo->n_info_i = 2; lo->n_info_f = A * 2 * s.dim_c; break;
         case MPE_SCN_PREDATOR_PREY: lo->n_info_i = A + 1; break;
+        case MPE_SCN_COLLECTOR: lo->n_info_i = 3 * A + 1; break;
         default: break;
     }
     lo->n_aux = s.n_aux();
@@ -217,7 +234,7 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     s.scenario = spec->scenario; s.A = A; s.L = L; s.dim_c = spec->dim_c; s.collaborative = spec->collaborative ? 1 : 0;
     s.physics = spec->physics;
     if (s.physics != MPE_PHYSICS_CORE && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: unknown physics %d", s.physics); }
-    const bool new_core_scn = spec->scenario == MPE_SCN_PREDATOR_PREY || spec->scenario == MPE_SCN_CONSENSUS;
+    const bool new_core_scn = spec->scenario == MPE_SCN_PREDATOR_PREY || spec->scenario == MPE_SCN_CONSENSUS || spec->scenario == MPE_SCN_COLLECTOR;
     if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE && !new_core_scn) {
         delete h;
         return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey and consensus only");

@@ -28,7 +28,7 @@ struct HostSpec {
         switch (scenario) {
             case MPE_SCN_ADVERSARY: case MPE_SCN_PUSH: case MPE_SCN_SPEAKER_LISTENER: case MPE_SCN_CONSENSUS: return 1;
             case MPE_SCN_REFERENCE: case MPE_SCN_CRYPTO: return 2;
-            case MPE_SCN_PREDATOR_PREY: return 3;
+            case MPE_SCN_PREDATOR_PREY: case MPE_SCN_COLLECTOR: return 3;
             default: return 0;
         }
     }
@@ -82,6 +82,7 @@ struct StepArgs {
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112
 // from U(-0.9,0.9).
 inline double landmark_limit(const HostSpec& s) {
+    if (s.scenario == MPE_SCN_COLLECTOR) return 0.95;        // collector.py:123-127
     return (s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM || s.scenario == MPE_SCN_PREDATOR_PREY) ? 0.9 : 1.0;
 }
 

@@ -274,19 +274,21 @@ __host__ __device__ inline int reset_aux(const RS& rs, unsigned long long b, int
     return (int)(((uint64_t)r[k] * (uint64_t)n_landmarks) >> 32);
 }
 
-// Random 32-bit word of world `b` in episode rs.episode (word 0 of the block the landmark indices
-// come from): seeds the per-world respawn stream of scenarios whose post_step draws positions.
+// Random 32-bit word of world `b` in episode rs.episode (word `w` of the block the landmark indices
+// come from); word 0 seeds the per-world respawn stream of scenarios whose post_step draws positions.
 template <class RS>
-__host__ __device__ inline int reset_stream_key(const RS& rs, unsigned long long b) {
+__host__ __device__ inline int reset_stream_key(const RS& rs, unsigned long long b, int w = 0) {
     uint32_t r[4];
     Philox::block(rs.seed, b, rs.episode * 256ull + 255ull, r);
-    return (int)r[0];
+    return (int)r[w];
 }
 
-// n-th respawn position of world `b`, U(-lim, lim)^2, from the world's own stream key.
-__host__ __device__ inline V2<double> respawn_draw(int key, unsigned long long b, int n, double lim) {
+// n-th respawn position of world `b`, U(-lim, lim)^2, from the world's own stream key.  *spare
+// receives the low 5 bits of the block's first word, which the position does not use.
+__host__ __device__ inline V2<double> respawn_draw(int key, unsigned long long b, int n, double lim, int* spare = nullptr) {
     uint32_t r[4];
     Philox::block(0x5eed5eed00000000ull | (uint32_t)key, b, (unsigned long long)(uint32_t)n, r);
+    if (spare) *spare = (int)(r[0] & 31u);
     V2<double> d;
     d.x = -lim + (lim + lim) * Philox::u01(r[0], r[1]);
     d.y = -lim + (lim + lim) * Philox::u01(r[2], r[3]);

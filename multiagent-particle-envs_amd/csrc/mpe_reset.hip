@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, i
             pos[at(2 * e, 2 * E)] = (T)d.x;
             pos[at(2 * e + 1, 2 * E)] = (T)d.y;
         }
-        for (int k = 0; k < n_aux; ++k) aux[at(k, n_aux)] = reset_aux(rs, (unsigned long long)b, k, E - A);
+        for (int k = 0; k < n_aux; ++k)
+            aux[at(k, n_aux)] = scenario == MPE_SCN_COLLECTOR ? CollectorCfg::initial_aux(rs, (unsigned long long)b, k)
+                                                              : reset_aux(rs, (unsigned long long)b, k, E - A);
     }
     for (int r = 0; r < 2 * A; ++r) vel[at(r, 2 * A)] = T(0);
     for (int r = 0; r < comm_rows; ++r) comm[at(r, comm_rows)] = T(0);

@@ -38,6 +38,7 @@ struct CfgBase {
     // > 1: the observation row is produced and streamed out in this many equal column chunks (one LDS
     // tile of a chunk's width instead of the whole row), through observe_prepare / observe_chunk<C>
     static constexpr int OBS_CHUNKS = 1;
+    static constexpr int CHUNK_MAX = 0;     // widest chunk; chunk c covers columns [chunk_offset(c), + chunk_width(c))
     __host__ __device__ static constexpr bool movable(int) { return true; }    // Agent.movable
     __host__ __device__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
     // Entity whose magnitudes (size, mass, sensitivity, speed limit ...) entity e shares: a scenario whose
@@ -674,7 +675,9 @@ struct PredatorPreyCfg : CfgBase {
     // adversaries, good agents, the barrier, foods and forests each share their properties (:39-41,49,58,67)
     __host__ __device__ static constexpr int rep(int e) { return e < N_ADV ? 0 : (e < A ? N_ADV : (e == BARRIER ? BARRIER : (e < FOREST0 ? FOOD0 : FOREST0))); }
     // one agent's 45 values at a time: a 64 x 315 tile (80 KB in float32) would leave one wave per CU
-    static constexpr int OBS_CHUNKS = A;
+    static constexpr int OBS_CHUNKS = A, CHUNK_MAX = OBS_DIM;
+    __host__ __device__ static constexpr int chunk_width(int) { return OBS_DIM; }
+    __host__ __device__ static constexpr int chunk_offset(int c) { return c * OBS_DIM; }
 
     __device__ static __forceinline__ bool holds(int flags, int i) { return (flags >> (3 + i - MEMBER0)) & 1; }
 
@@ -908,6 +911,310 @@ struct PredatorPreyCfg : CfgBase {
                 d[f] = reset_draw(rs, b, f, false, attempt);
             }
         }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// collector on the new_core physics: collectors 0-5 pick up treasures of two types and carry them to
+// the deposit of that type (agents 6, 7); every agent collides; 6 treasures; no walls
+// (multiagent/scenarios/collector.py).  aux[0] holds the state post_step rewrites: bits 2a, 2a+1 =
+// what collector a holds (0 nothing, 1 + type), bit 12+l = type of treasure l, bit 18+l = treasure l
+// is alive; aux[1] / aux[2] are the key and the position of the world's respawn stream.  Distances
+// are those of the cache World.step fills (new_core.py:147-170): vect[a, b] = p_a - p_b.
+// ------------------------------------------------------------------------------------------
+struct CollectorCfg : CfgBase {
+    static constexpr int NC = 6, A = 8, L = 6, E = 14;
+    static constexpr int DIM_C = 0, S = 0, N_ACT = 8;
+    static constexpr int OBS_COL = 4 + 2 + (A - 1) * 8 + L * 4, OBS_DEP = 4 + (A - 1) * 8 + L * 4;      // 86, 84
+    static constexpr int OBS_TOTAL = NC * OBS_COL + (A - NC) * OBS_DEP;
+    static constexpr int NI = 3 * A + 1, NF = 0, N_AUX = 3;       // info: (collected, deposited, collisions) per agent, the state word
+    static constexpr bool DYNAMIC = true, NEW_CORE = true;
+    static constexpr int OBS_CHUNKS = A, CHUNK_MAX = OBS_COL;
+    __host__ __device__ static constexpr int chunk_width(int c) { return c < NC ? OBS_COL : OBS_DEP; }
+    __host__ __device__ static constexpr int chunk_offset(int c) { return c < NC ? c * OBS_COL : NC * OBS_COL + (c - NC) * OBS_DEP; }
+    __host__ __device__ static constexpr bool collides(int e) { return e < A; }       // :40,57
+    // collectors, deposits and treasures each share their properties (:44-47,59)
+    __host__ __device__ static constexpr int rep(int e) { return e < NC ? 0 : (e < A ? NC : A); }
+
+    __device__ static __forceinline__ int held(int st, int a) { return ((st >> (2 * a)) & 3) - 1; }      // -1: nothing, else the type
+    __device__ static __forceinline__ int ttype(int st, int l) { return (st >> (12 + l)) & 1; }
+    __device__ static __forceinline__ bool alive(int st, int l) { return (st >> (18 + l)) & 1; }
+
+    template <typename T, class P>
+    __device__ static __forceinline__ int observe_prepare(const V2<T> (&)[E], const P&) { return 0; }
+
+    // sorted(zip(distance, index)): ascending distance, ties by index (collector.py:272-278)
+    template <typename T> __device__ static __forceinline__ bool after(T ka, int ia, T kb, int ib) { return ka > kb || (ka == kb && ia > ib); }
+
+    // observation() of agent I, collector.py:268-295; cast to float32
+    template <typename T, int I>
+    __device__ static __forceinline__ void observe_chunk(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, int, T* row) {
+        const int st = aux[0];
+        V2<T> me = pos[I];
+        asm volatile("" : "+v"(me.x), "+v"(me.y));      // keeps this chunk's arithmetic between its barriers
+        int k = 0;
+        row[k++] = round_f32(me.x); row[k++] = round_f32(me.y);
+        row[k++] = round_f32(vel[I].x); row[k++] = round_f32(vel[I].y);
+        if (I < NC) {
+            const int h = held(st, I);
+            row[k++] = (h == 0) ? T(1) : T(0); row[k++] = (h == 1) ? T(1) : T(0);
+        }
+        // ---- the 7 other agents, nearest first: offset, velocity, encoding (:257-266) ----
+        {
+            constexpr int N = A - 1;
+            T key[N], dx[N], dy[N], vx[N], vy[N];
+            int idx[N], code[N];        // code: 0 collector holding nothing, 1 / 2 holding type 0 / 1, 3 / 4 deposit of type 0 / 1
+            int n = 0;
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == I) continue;
+                dx[n] = pos[j].x - me.x; dy[n] = pos[j].y - me.y;
+                key[n] = norm2<T>(dx[n], dy[n]);
+                vx[n] = vel[j].x; vy[n] = vel[j].y;
+                idx[n] = j;
+                code[n] = j < NC ? held(st, j) + 1 : 3 + (j - NC);
+                ++n;
+            }
+            auto ce = [&](int a, int b) {
+                const bool sw = after<T>(key[a], idx[a], key[b], idx[b]);
+                T t;
+                int u;
+                t = key[a]; key[a] = sw ? key[b] : t; key[b] = sw ? t : key[b];
+                t = dx[a]; dx[a] = sw ? dx[b] : t; dx[b] = sw ? t : dx[b];
+                t = dy[a]; dy[a] = sw ? dy[b] : t; dy[b] = sw ? t : dy[b];
+                t = vx[a]; vx[a] = sw ? vx[b] : t; vx[b] = sw ? t : vx[b];
+                t = vy[a]; vy[a] = sw ? vy[b] : t; vy[b] = sw ? t : vy[b];
+                u = idx[a]; idx[a] = sw ? idx[b] : u; idx[b] = sw ? u : idx[b];
+                u = code[a]; code[a] = sw ? code[b] : u; code[b] = sw ? u : code[b];
+            };
+            // 16-comparator network for 7 keys
+            ce(0, 6); ce(2, 3); ce(4, 5); ce(0, 2); ce(1, 4); ce(3, 6); ce(0, 1); ce(2, 5); ce(3, 4);
+            ce(1, 2); ce(4, 6); ce(2, 3); ce(4, 5); ce(1, 2); ce(3, 4); ce(5, 6);
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+                row[k++] = round_f32(dx[q]); row[k++] = round_f32(dy[q]);
+                row[k++] = round_f32(vx[q]); row[k++] = round_f32(vy[q]);
+                row[k++] = (code[q] == 3) ? T(1) : T(0); row[k++] = (code[q] == 4) ? T(1) : T(0);
+                row[k++] = (code[q] == 1) ? T(1) : T(0); row[k++] = (code[q] == 2) ? T(1) : T(0);
+            }
+        }
+        // ---- the 6 treasures, nearest first: offset, type (:275-278,290-293) ----
+        {
+            T key[L], dx[L], dy[L];
+            int idx[L], ty[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                dx[l] = pos[A + l].x - me.x; dy[l] = pos[A + l].y - me.y;
+                key[l] = norm2<T>(dx[l], dy[l]);
+                idx[l] = l;
+                ty[l] = ttype(st, l);
+            }
+            auto ce = [&](int a, int b) {
+                const bool sw = after<T>(key[a], idx[a], key[b], idx[b]);
+                T t;
+                int u;
+                t = key[a]; key[a] = sw ? key[b] : t; key[b] = sw ? t : key[b];
+                t = dx[a]; dx[a] = sw ? dx[b] : t; dx[b] = sw ? t : dx[b];
+                t = dy[a]; dy[a] = sw ? dy[b] : t; dy[b] = sw ? t : dy[b];
+                u = idx[a]; idx[a] = sw ? idx[b] : u; idx[b] = sw ? u : idx[b];
+                u = ty[a]; ty[a] = sw ? ty[b] : u; ty[b] = sw ? u : ty[b];
+            };
+            // 12-comparator network for 6 keys
+            ce(0, 5); ce(1, 3); ce(2, 4); ce(1, 2); ce(3, 4); ce(0, 3); ce(2, 5); ce(0, 1); ce(2, 3); ce(4, 5); ce(1, 2); ce(3, 4);
+#pragma unroll
+            for (int q = 0; q < L; ++q) {
+                row[k++] = round_f32(dx[q]); row[k++] = round_f32(dy[q]);
+                row[k++] = (ty[q] == 0) ? T(1) : T(0); row[k++] = (ty[q] == 1) ? T(1) : T(0);
+            }
+        }
+    }
+
+    template <typename T, int C>
+    __device__ static __forceinline__ void observe_all(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, T* row) {
+        observe_chunk<T, C>(pos, vel, aux, 0, row + chunk_offset(C));
+        if constexpr (C + 1 < A) observe_all<T, C + 1>(pos, vel, aux, row);
+    }
+
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, const P&, T* row) {
+        observe_all<T, 0>(pos, vel, aux, row);
+    }
+
+    // reward() :165-255 (everything is paid to collector 0) and benchmark_data() :132-155
+    template <typename T, class P>
+    __device__ static __forceinline__ void score(const V2<T> (&pos)[E], const T*, const int* aux, const P& p, T* rew, bool want_info, int* info_i, T*) {
+        const int st = aux[0];
+        const T s_cc = p.size[rep(0)] + p.size[rep(0)], s_cd = p.size[rep(0)] + p.size[rep(NC)], s_ct = p.size[rep(0)] + p.size[rep(A)];
+        T d_cd[NC][A - NC];         // collector - deposit distances
+        bool hit_cd[NC][A - NC];
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int d = 0; d < A - NC; ++d) {
+                d_cd[a][d] = norm2<T>(pos[NC + d].x - pos[a].x, pos[NC + d].y - pos[a].y);
+                hit_cd[a][d] = d_cd[a][d] < s_cd;
+            }
+        // global rewards :239-255
+        int gdr = 0, gcr = 0;
+#pragma unroll
+        for (int d = 0; d < A - NC; ++d)
+#pragma unroll
+            for (int a = 0; a < NC; ++a) gdr += (held(st, a) == d && hit_cd[a][d]) ? 5 : 0;
+        T tmin[NC];                 // distance of collector a to its nearest live treasure
+        bool tany = false;
+        int n_touch[NC];            // treasures (dead ones at the origin included) collector a touches
+#pragma unroll
+        for (int a = 0; a < NC; ++a) { tmin[a] = T(0); n_touch[a] = 0; }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const bool live = alive(st, l);
+#pragma unroll
+            for (int a = 0; a < NC; ++a) {
+                const T d = norm2<T>(pos[A + l].x - pos[a].x, pos[A + l].y - pos[a].y);
+                const bool h = d < s_ct;
+                n_touch[a] += h ? 1 : 0;
+                if (live) {
+                    gcr += (h && held(st, a) < 0) ? 5 : 0;
+                    tmin[a] = (tany && !(d < tmin[a])) ? tmin[a] : d;       // Python min: first wins
+                }
+            }
+            tany = tany || live;
+        }
+        const T glob = (T)(gdr + gcr);
+        // deposit_reward :177-213 of both deposits
+        T main = T(0);
+#pragma unroll
+        for (int d = 0; d < A - NC; ++d) {
+            T r;
+            bool any = false;
+            T dmin = T(0);
+#pragma unroll
+            for (int a = 0; a < NC; ++a) {
+                if (held(st, a) != d) continue;
+                dmin = (any && !(d_cd[a][d] < dmin)) ? dmin : d_cd[a][d];
+                any = true;
+            }
+            if (any) {
+                r = T(0) - T(0.1) * dmin;
+            } else {
+                // nobody carries this type: norm of the mean offset of the collectors, summed nearest first
+                T key[NC], dx[NC], dy[NC];
+                int idx[NC];
+#pragma unroll
+                for (int a = 0; a < NC; ++a) {
+                    key[a] = d_cd[a][d]; dx[a] = pos[a].x - pos[NC + d].x; dy[a] = pos[a].y - pos[NC + d].y; idx[a] = a;
+                }
+                auto ce = [&](int a, int b) {
+                    const bool sw = after<T>(key[a], idx[a], key[b], idx[b]);
+                    T t;
+                    int u;
+                    t = key[a]; key[a] = sw ? key[b] : t; key[b] = sw ? t : key[b];
+                    t = dx[a]; dx[a] = sw ? dx[b] : t; dx[b] = sw ? t : dx[b];
+                    t = dy[a]; dy[a] = sw ? dy[b] : t; dy[b] = sw ? t : dy[b];
+                    u = idx[a]; idx[a] = sw ? idx[b] : u; idx[b] = sw ? u : idx[b];
+                };
+                ce(0, 5); ce(1, 3); ce(2, 4); ce(1, 2); ce(3, 4); ce(0, 3); ce(2, 5); ce(0, 1); ce(2, 3); ce(4, 5); ce(1, 2); ce(3, 4);
+                T sx = dx[0], sy = dy[0];
+#pragma unroll
+                for (int q = 1; q < NC; ++q) { sx = sx + dx[q]; sy = sy + dy[q]; }
+                sx = sx / T(NC); sy = sy / T(NC);
+                r = T(0) - T(0.1) * norm2<T>(sx, sy);
+            }
+            r = r + (T)gdr;
+#pragma unroll
+            for (int a = 0; a < NC; ++a) {
+                const int h = held(st, a);
+                if (h < 0) {
+                    if (tany) r = r - T(0.1) * tmin[a];
+                } else {
+                    r = r - T(0.1) * (h == 0 ? d_cd[a][0] : d_cd[a][1]);
+                }
+                r = r + glob;
+            }
+            main = (d == 0) ? r : main + r;
+        }
+        // collector_reward :215-229 and the collision counts
+        int n_coll[NC];
+        int total = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) n_coll[a] = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int b = a + 1; b < NC; ++b) {
+                const bool h = norm2<T>(pos[a].x - pos[b].x, pos[a].y - pos[b].y) < s_cc;
+                n_coll[a] += h ? 1 : 0;
+                n_coll[b] += h ? 1 : 0;
+            }
+#pragma unroll
+        for (int a = 0; a < NC; ++a) total += n_coll[a];
+        rew[0] = T(0) + main + (T)(-5 * total);
+#pragma unroll
+        for (int i = 1; i < A; ++i) rew[i] = T(0);
+        if (want_info) {
+#pragma unroll
+            for (int a = 0; a < NC; ++a) {
+                info_i[3 * a] = held(st, a) < 0 ? n_touch[a] : 0;
+                info_i[3 * a + 1] = 0;
+                info_i[3 * a + 2] = n_coll[a];
+            }
+#pragma unroll
+            for (int d = 0; d < A - NC; ++d) {
+                int c = 0;
+#pragma unroll
+                for (int a = 0; a < NC; ++a) c += (held(st, a) == d && hit_cd[a][d]) ? 1 : 0;
+                info_i[3 * (NC + d)] = 0;
+                info_i[3 * (NC + d) + 1] = c;
+                info_i[3 * (NC + d) + 2] = 0;
+            }
+            info_i[3 * A] = st;
+        }
+    }
+
+    // post_step() :84-110, after the step's observations and rewards are taken
+    template <class Pos, class P>
+    __device__ static __forceinline__ void post_step(Pos& pos, int* aux, const P& p, unsigned long long b) {
+        typedef decltype(pos[0].x) T;
+        int st = aux[0];
+        const T s_cd = p.size[rep(0)] + p.size[rep(NC)], s_ct = p.size[rep(0)] + p.size[rep(A)];
+        bool at_deposit[NC][A - NC];
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int d = 0; d < A - NC; ++d) at_deposit[a][d] = touching<T>(pos[a], pos[NC + d], s_cd);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (alive(st, l)) {
+                bool taken = false;
+#pragma unroll
+                for (int a = 0; a < NC; ++a) {
+                    const bool pick = !taken && held(st, a) < 0 && touching<T>(pos[A + l], pos[a], s_ct);
+                    if (pick) { st |= (1 + ttype(st, l)) << (2 * a); taken = true; }
+                }
+                if (taken) {
+                    st &= ~(1 << (18 + l));
+                    pos[A + l].x = T(-0.0); pos[A + l].y = T(-0.0);
+                }
+            } else {
+                int spare;
+                const V2<double> d = respawn_draw(aux[1], b, aux[2], 0.95, &spare);
+                aux[2] += 1;
+                pos[A + l].x = (T)d.x; pos[A + l].y = (T)d.y;
+                st = (st & ~(1 << (12 + l))) | ((spare & 1) << (12 + l)) | (1 << (18 + l));
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const int h = held(st, a);
+            if (h >= 0 && (h == 0 ? at_deposit[a][0] : at_deposit[a][1])) st &= ~(3 << (2 * a));
+        }
+        aux[0] = st;
+    }
+
+    // reset_world :112-130: nobody holds anything, every treasure alive with a fresh type; a fresh respawn stream
+    template <class RS>
+    __host__ __device__ static int initial_aux(const RS& rs, unsigned long long b, int k) {
+        return k == 0 ? (((reset_stream_key(rs, b, 1) & 63) << 12) | (63 << 18)) : (k == 1 ? reset_stream_key(rs, b) : 0);
     }
 };
 

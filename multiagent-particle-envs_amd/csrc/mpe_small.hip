@@ -11,7 +11,7 @@ bool small_supported(const HostSpec& s) {
     return (s.scenario == MPE_SCN_SPREAD && s.A == 3 && s.L == 3) || s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM ||
            s.scenario == MPE_SCN_SIMPLE || s.scenario == MPE_SCN_ADVERSARY || s.scenario == MPE_SCN_PUSH ||
            s.scenario == MPE_SCN_SPEAKER_LISTENER || s.scenario == MPE_SCN_REFERENCE || s.scenario == MPE_SCN_CRYPTO ||
-           s.scenario == MPE_SCN_PREDATOR_PREY;
+           s.scenario == MPE_SCN_PREDATOR_PREY || s.scenario == MPE_SCN_COLLECTOR;
 }
 
 hipError_t launch_small(const HostSpec& s, long long B, int dtype, int mode, const StepArgs& a, hipStream_t st) {

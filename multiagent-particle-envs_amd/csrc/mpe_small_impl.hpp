@@ -70,18 +70,18 @@ struct Tile {
 // block at gbase (row stride OT), 4 bytes per lane.
 template <typename T, class Cfg, int C, int EPW>
 struct ObsChunks {
-    static constexpr int W = Cfg::OBS_TOTAL / Cfg::OBS_CHUNKS;
+    static constexpr int W = Cfg::chunk_width(C), S = Cfg::CHUNK_MAX, COL0 = Cfg::chunk_offset(C);
     template <class Pos, class Vel, class Ctx>
     static __device__ __forceinline__ void run(const Pos& pos, const Vel& vel, const int* aux, const Ctx& ctx, T* tile, T* gbase, int lane,
                                                int tile_lane, bool active, int nvalid) {
-        if (active) Cfg::template observe_chunk<T, C>(pos, vel, aux, ctx, tile + tile_lane * W);
+        if (active) Cfg::template observe_chunk<T, C>(pos, vel, aux, ctx, tile + tile_lane * S);
         __syncthreads();
         const int n = nvalid * W;
 #pragma unroll
         for (int it = 0; it < (EPW * W + 63) / 64; ++it) {
             const int g = it * 64 + lane;
             const int r = g / W;
-            if (g < n) gbase[(long long)r * Cfg::OBS_TOTAL + C * W + (g - r * W)] = tile[g];
+            if (g < n) gbase[(long long)r * Cfg::OBS_TOTAL + COL0 + (g - r * W)] = tile[r * S + (g - r * W)];
         }
         __syncthreads();
         if constexpr (C + 1 < Cfg::OBS_CHUNKS)
@@ -114,8 +114,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
     constexpr int NI = Cfg::NI > 0 ? Cfg::NI : 1, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C, NX = Cfg::N_AUX;
     constexpr int NC = Cfg::S * Cfg::DIM_C;      // comm state values: the speakers' utterances in agent order
-    static_assert(OT % Cfg::OBS_CHUNKS == 0, "observation chunks are equal column ranges");
-    constexpr int OW = OT / Cfg::OBS_CHUNKS;        // columns held by the observation tile
+    constexpr int OW = Cfg::OBS_CHUNKS > 1 ? Cfg::CHUNK_MAX : OT;        // columns held by the observation tile
     constexpr bool LIN = Cfg::OBS_CHUNKS > 1 || ((OW * (int)sizeof(T) / 4) % 16) != 0;
     using ObsTile = Tile<T, OW, LIN, EPW>;
     using RewTile = Tile<T, A, true, EPW>;
@@ -556,6 +555,8 @@ hipError_t launch_small_t(const HostSpec& s, long long B, int mode, const StepAr
             return launch_cfg<T, CryptoCfg, true>(s, B, mode, a, st);
         case MPE_SCN_PREDATOR_PREY:
             return launch_cfg<T, PredatorPreyCfg, true>(s, B, mode, a, st);
+        case MPE_SCN_COLLECTOR:
+            return launch_cfg<T, CollectorCfg, true>(s, B, mode, a, st);
     }
     return hipErrorInvalidValue;
 }

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "libmpe_hip.so")
 MPE_F32, MPE_F64 = 0, 1
 SCN_NONE, SCN_SPREAD, SCN_TAG, SCN_WORLD_COMM, SCN_SIMPLE, SCN_ADVERSARY, SCN_PUSH = 0, 1, 2, 3, 4, 5, 6
 SCN_SPEAKER_LISTENER, SCN_REFERENCE, SCN_CRYPTO, SCN_PREDATOR_PREY, SCN_CONSENSUS = 7, 8, 9, 10, 11
+SCN_COLLECTOR = 12
 PHYSICS_CORE, PHYSICS_NEW_CORE = 0, 1
 MAX_AGENTS = 64
 MAX_LANDMARKS = 64

@@ -191,6 +191,18 @@ def consensus_spec():
                      ghost=np.ones(6, bool), new_core=True, accel=np.full(6, np.nan), collaborative=True)
 
 
+def collector_spec():
+    """collector (multiagent/scenarios/collector.py:8-71) on the new_core physics: 6 collectors (size .05,
+    mass 1) and 2 deposits (size .075, mass 2.25), colliding ghosts with accel 1.5 and max_speed 1; 6
+    treasures (size .025) that neither collide nor move; no walls."""
+    col = np.arange(8) < 6
+    return WorldSpec(_lib.SCN_COLLECTOR, 8, 6, 2, size=np.r_[np.where(col, 0.05, 0.075), np.full(6, 0.025)],
+                     mass=np.r_[np.where(col, 1.0, 2.25), np.ones(6)], movable=np.r_[np.ones(8, bool), np.zeros(6, bool)],
+                     collide=np.r_[np.ones(8, bool), np.zeros(6, bool)], sensitivity=np.full(8, 1.5), max_speed=np.ones(8),
+                     silent=np.ones(8, bool), adversary=np.zeros(8, bool), leader=np.zeros(8, bool), name="collector",
+                     ghost=np.ones(8, bool), new_core=True, accel=np.full(8, 1.5))
+
+
 def physics_spec(n_agents, n_landmarks, dim_c, size, mass, collide, sensitivity, max_speed, silent, walls=(), ghost=None,
                  movable=None, **world):
     """A world stepped by ``mpe_world_step`` only (World.step, multiagent/core.py:142-158, or with
@@ -228,4 +240,6 @@ def make_spec(name, **kw):
         return predator_prey_spec()
     if name == "consensus":
         return consensus_spec()
+    if name == "collector":
+        return collector_spec()
     raise ValueError("no batched kernel for scenario %r" % (name,))

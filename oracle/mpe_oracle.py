@@ -1236,3 +1236,20 @@ def collector_env_step(spec: Spec, pos, vel, actions, holding, ttype, alive, res
     for b in range(B):
         collector_post_step1(spec, pos[b], holding[b], ttype[b], alive[b], respawn_pos[b], respawn_type[b])
     return pos, vel, obs, rew, info, holding, ttype, alive
+
+
+def device_respawn_type(key, b, n):
+    """Type bit drawn with the n-th respawn of world(s) b: bit 0 of the block's first word."""
+    k = np.uint64(0x5EED5EED00000000) | (np.asarray(key).astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF))
+    r = philox4x32(k, b, np.asarray(n).astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF))
+    return (r[..., 0] & np.uint32(1)).astype(np.int64)
+
+
+def collector_device_reset(spec: Spec, seed, episode, B):
+    """collector worlds as the device reset draws them: agents U(-1,1)^2, treasures U(-0.95,0.95)^2, treasure
+    types = bits 0..5 of word 1 of the aux block, stream key = word 0.  Returns (pos, ttype [B, 6], key [B])."""
+    b = np.arange(B, dtype=np.uint64)
+    pos = np.stack([device_reset_draw(seed, b, episode, e, 1.0 if e < spec.A else 0.95) for e in range(spec.E)], axis=1)
+    w = device_aux_words(seed, b, episode)
+    ttype = ((w[:, 1, None].astype(np.int64) >> np.arange(6)) & 1)
+    return pos, ttype, w[:, 0].astype(np.int32)

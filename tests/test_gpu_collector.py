@@ -1,0 +1,216 @@
+"""collector (new_core physics with mass-ratio contacts, sorted-nearest observations, pooled reward,
+pick-up / hand-over / respawn state machine) on the GPU.
+
+As for simple_predator_prey the reference draws respawns from a numpy generator and the kernel from a
+counter-based stream: the fixture is replayed teacher-forced and free-running until a world's first
+respawn; whole free-running episodes are checked against the oracle evaluating the device's stream.
+Bars as in tests/test_gpu_parity.py: float64 1e-9 relative (1e-12 floor), float32 1e-4; state bits and
+benchmark counts bit-exact.
+"""
+import numpy as np
+import pytest
+
+import mpe_oracle as orc
+from conftest import load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+CASE = "collector"
+
+
+def _close(a, b, rtol, atol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def _env(B, dtype, info=True, **kw):
+    import mpe_hip
+    return mpe_hip.BatchedEnv(CASE, B, dtype=dtype, device="cuda:0", info=info, **kw)
+
+
+def _word(holding, ttype, alive):
+    h = ((holding + 1).astype(np.int64) << (2 * np.arange(6))).sum(axis=1)
+    return h | (ttype.astype(np.int64) << (12 + np.arange(6))).sum(axis=1) | (alive.astype(np.int64) << (18 + np.arange(6))).sum(axis=1)
+
+
+def _aux(holding, ttype, alive, key=None, count=None):
+    B = holding.shape[0]
+    return np.stack([_word(holding, ttype, alive), np.zeros(B, np.int64) if key is None else key, np.zeros(B, np.int64) if count is None else count], axis=1)
+
+
+def _unword(w):
+    w = np.asarray(w).astype(np.int64)
+    return ((w[:, None] >> (2 * np.arange(6))) & 3) - 1, (w[:, None] >> (12 + np.arange(6))) & 1, ((w[:, None] >> (18 + np.arange(6))) & 1).astype(bool)
+
+
+def _state_before(g, t):
+    A = g["pos"].shape[2]
+    pos = g["pos0"].copy()
+    if t == 0:
+        return pos, g["vel0"], g["holding0"], g["ttype0"], g["alive0"]
+    pos[:, :A] = g["pos"][t - 1]
+    pos[:, A:] = g["treasure_pos"][t - 1]
+    return pos, g["vel"][t - 1], g["holding"][t - 1], g["ttype"][t - 1], g["alive"][t - 1]
+
+
+def test_layout():
+    g = load_golden(CASE)
+    env = _env(8, torch.float64)
+    assert env.obs_dims == list(g["obs_dims"]) and env.n_act == 8 and env.layout.n_aux == 3 and env.layout.n_info_i == 25
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", [("float64", 1e-9, 1e-12), ("float32", 1e-4, 1e-4)])
+def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
+    g = load_golden(CASE)
+    T, B, A = g["actions"].shape
+    env = _env(B, getattr(torch, dtype))
+    pos, vel, holding, ttype, alive = _state_before(g, 0)
+    env.set_state(pos, vel, goal=_aux(holding, ttype, alive))
+    env.observe()
+    exact = dtype == "float64"
+    if exact:
+        assert _close(env.obs.cpu().numpy(), g["obs0"], rtol, atol)
+    for t in range(T):
+        pos, vel, holding, ttype, alive = _state_before(g, t)
+        env.set_state(pos, vel, goal=_aux(holding, ttype, alive))
+        obs, rew, done, (info_i, _) = env.step(torch.as_tensor(g["actions"][t]))
+        gp, gv, _ = env.get_state()
+        assert _close(gp[:, :A], g["pos"][t], rtol, atol), (t, np.abs(gp[:, :A] - g["pos"][t]).max())
+        assert _close(gv, g["vel"][t], rtol * 10, atol * 10), t
+        ii = info_i.cpu().numpy()
+        h2, t2, a2 = _unword(env.aux[0].cpu().numpy())
+        if exact:
+            assert _close(obs.cpu().numpy(), g["obs"][t], rtol, atol), (t, np.abs(obs.cpu().numpy() - g["obs"][t]).max())
+            assert _close(rew.cpu().numpy(), g["rew"][t], rtol, atol), (t, np.abs(rew.cpu().numpy() - g["rew"][t]).max())
+            assert np.array_equal(ii[:, :3 * A].reshape(B, A, 3), g["info"][t]) and np.array_equal(ii[:, 3 * A], _word(holding, ttype, alive))
+            assert np.array_equal(h2, g["holding"][t]) and np.array_equal(a2, g["alive"][t]), t
+            keep = alive & a2
+            assert np.array_equal(t2[keep], g["ttype"][t][keep])
+        else:
+            # float32 may reorder two near-equidistant neighbours or flip a knife-edge contact of the fixture
+            ok = np.all(np.abs(obs.cpu().numpy() - g["obs"][t]) <= atol + rtol * np.abs(g["obs"][t]), axis=1)
+            assert ok.mean() > 0.85, (t, ok.mean())
+            assert np.mean(np.all(h2 == g["holding"][t], axis=1)) > 0.9
+        assert not done.any()
+        tre = gp[:, A:]
+        assert np.array_equal(tre[alive & a2], pos[:, A:][alive & a2].astype(tre.dtype))
+        assert np.all(tre[~a2] == 0.0)                                  # taken: parked at the origin
+        assert np.all(np.abs(tre[~alive]) <= 0.95) and a2[~alive].all()  # respawned inside the arena
+        assert np.array_equal(env.aux[2].cpu().numpy(), (~alive).sum(axis=1))
+
+
+def test_free_running_until_first_respawn_matches_reference():
+    g = load_golden(CASE)
+    T, B, A = g["actions"].shape
+    env = _env(B, torch.float64)
+    env.set_state(g["pos0"], g["vel0"], goal=_aux(g["holding0"], g["ttype0"], g["alive0"]))
+    clean = g["alive0"].all(axis=1)
+    checked = 0
+    for t in range(T):
+        obs, rew, done, _ = env.step(torch.as_tensor(g["actions"][t]))
+        gp, gv, _ = env.get_state()
+        assert _close(gp[clean][:, :A], g["pos"][t][clean], 1e-9, 1e-12), t
+        assert _close(obs.cpu().numpy()[clean], g["obs"][t][clean], 1e-9, 1e-12), t
+        assert _close(rew.cpu().numpy()[clean], g["rew"][t][clean], 1e-9, 1e-12), t
+        h2, _, a2 = _unword(env.aux[0].cpu().numpy())
+        assert np.array_equal(h2[clean], g["holding"][t][clean]) and np.array_equal(a2[clean], g["alive"][t][clean])
+        checked += int(clean.sum())
+        clean &= g["alive"][t].all(axis=1)
+    assert checked > 300 and clean.sum() >= 4
+
+
+def test_device_reset_matches_the_oracle_stream():
+    spec = orc.make_spec(CASE)
+    B = 4000
+    env = _env(B, torch.float64)
+    env._episode = 2
+    env.reset(seed=31, observe=False)
+    pos, vel, _ = env.get_state()
+    want, ttype, key = orc.collector_device_reset(spec, 31, 2, B)
+    assert np.array_equal(pos, want) and not vel.any()
+    aux = env.aux.cpu().numpy()
+    h, t, a = _unword(aux[0])
+    assert (h == -1).all() and a.all() and np.array_equal(t, ttype) and 0.45 < t.mean() < 0.55
+    assert np.array_equal(aux[1], key) and not aux[2].any()
+    assert np.abs(pos[:, spec.A:]).max() <= 0.95 < np.abs(pos[:, :spec.A]).max()
+
+
+@pytest.mark.parametrize("mode", ["step", "rollout", "episode"])
+def test_free_running_episode_against_oracle(mode):
+    spec = orc.make_spec(CASE)
+    A, L = spec.A, spec.L
+    B, T = 600, 25
+    env = _env(B, torch.float64)
+    rng = np.random.RandomState(3)
+    acts = rng.randint(0, 5, (T, B, A)).astype(np.int32)
+    holding = np.full((B, 6), -1, np.int64)
+    if mode == "episode":
+        out = env.rollout(torch.as_tensor(acts, device="cuda:0"), reset_seed=9)
+        pos, ttype, key = orc.collector_device_reset(spec, 9, 0, B)
+    else:
+        env.reset(seed=9, observe=False)
+        pos = env.get_state()[0]
+        key = env.aux[1].cpu().numpy()
+        _, ttype, _ = _unword(env.aux[0].cpu().numpy())
+        # start many worlds mid-game: collectors on treasures, carriers next to their deposit
+        pos[::2, 0] = pos[::2, A] + 0.01
+        pos[::3, 1] = pos[::3, A + 1] - 0.02
+        holding[::4, 2] = 1
+        pos[::4, 2] = pos[::4, 7] + 0.03
+        env.set_state(pos, np.zeros((B, A, 2)), goal=_aux(holding, ttype, np.ones((B, L), bool), key=key))
+        if mode == "rollout":
+            out = env.rollout(torch.as_tensor(acts, device="cuda:0"))
+    vel = np.zeros((B, A, 2))
+    alive = np.ones((B, L), bool)
+    count = np.zeros(B, np.int64)
+    bidx = np.arange(B, dtype=np.uint64)
+    n_pick = n_hand = 0
+    for t in range(T):
+        resp, rtype = np.zeros((B, L, 2)), np.zeros((B, L), np.int64)
+        c = count.copy()
+        for l in range(L):                       # the stream is consumed in treasure order
+            dead = ~alive[:, l]
+            resp[dead, l] = orc.device_respawn_draw(key[dead], bidx[dead], c[dead])
+            rtype[dead, l] = orc.device_respawn_type(key[dead], bidx[dead], c[dead])
+            c += dead
+        count = c
+        before_alive, before_hold = alive.copy(), holding.copy()
+        pos, vel, obs, rew, info, holding, ttype, alive = orc.collector_env_step(spec, pos, vel, acts[t], holding, ttype, alive, resp, rtype)
+        n_pick += int((before_alive & ~alive).sum())
+        n_hand += int(((before_hold >= 0) & (holding < 0)).sum())
+        if mode == "step":
+            g_obs, g_rew, _, (ii, _) = env.step(torch.as_tensor(acts[t]))
+            g_obs, g_rew = g_obs.cpu().numpy(), g_rew.cpu().numpy()
+            gp, gv, _ = env.get_state()
+            assert _close(gp, pos, 1e-9, 1e-12) and _close(gv, vel, 1e-9, 1e-12), t
+            assert np.array_equal(env.aux[0].cpu().numpy(), _word(holding, ttype, alive)) and np.array_equal(env.aux[2].cpu().numpy(), count), t
+            assert np.array_equal(ii.cpu().numpy()[:, :3 * A].reshape(B, A, 3), info), t
+        else:
+            g_obs, g_rew = out["obs"][t].cpu().numpy(), out["rew"][t].cpu().numpy()
+        assert _close(g_obs, obs, 1e-9, 1e-12), (mode, t, np.abs(g_obs - obs).max())
+        assert _close(g_rew, rew, 1e-9, 1e-12), (mode, t, np.abs(g_rew - rew).max())
+    gp, gv, _ = env.get_state()
+    assert _close(gp, pos, 1e-9, 1e-12) and _close(gv, vel, 1e-9, 1e-12)
+    assert np.array_equal(env.aux[0].cpu().numpy(), _word(holding, ttype, alive)) and np.array_equal(env.aux[2].cpu().numpy(), count)
+    assert n_pick > (5 if mode == "episode" else 300), n_pick
+    if mode != "episode":
+        assert n_hand > 10, n_hand
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_rollout_and_episode_equal_stepping(dtype):
+    dt = getattr(torch, dtype)
+    B, T = 1000, 25
+    e1, e2, e3 = _env(B, dt), _env(B, dt), _env(B, dt)
+    a = torch.randint(0, 5, (T, B, 8), dtype=torch.int32, device="cuda:0", generator=torch.Generator("cuda:0").manual_seed(5))
+    e1.reset(seed=11, observe=False)
+    e2.reset(seed=11, observe=False)
+    out2 = e2.rollout(a)
+    out3 = e3.rollout(a, reset_seed=11)
+    for t in range(T):
+        obs, rew, done, (ii, _) = e1.step(a[t])
+        assert torch.equal(obs, out2["obs"][t]) and torch.equal(rew, out2["rew"][t]) and torch.equal(ii, out2["info_i"][t]), t
+    for k in ("obs", "rew", "done", "info_i"):
+        assert torch.equal(out2[k], out3[k]), k
+    assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.pos, e3.pos) and torch.equal(e1.vel, e3.vel) and torch.equal(e1.aux, e3.aux)
+    assert torch.equal(e1.aux, e2.aux)

@@ -25,3 +25,4 @@ run reference_B262144 --scenario simple_reference --envs 262144 --steps 1000 --w
 run crypto_B262144 --scenario simple_crypto --envs 262144 --steps 1000 --warmup 100
 run predator_prey_B131072 --scenario simple_predator_prey --envs 131072 --steps 500 --warmup 50
 run consensus_B65536 --scenario consensus --envs 65536 --steps 500 --warmup 50
+run collector_B65536 --scenario collector --envs 65536 --steps 250 --warmup 50
