@@ -17,4 +17,4 @@ def load(name):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         return mod
-    raise FileNotFoundError("no scenario %r (built in: consensus, simple, simple_adversary, simple_crypto, simple_predator_prey, simple_push, simple_reference, simple_speaker_listener, simple_spread, simple_tag, simple_world_comm)" % (name,))
+    raise FileNotFoundError("no scenario %r (built in: collector, consensus, simple, simple_adversary, simple_crypto, simple_predator_prey, simple_push, simple_reference, simple_speaker_listener, simple_spread, simple_tag, simple_world_comm)" % (name,))

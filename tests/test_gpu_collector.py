@@ -214,3 +214,37 @@ def test_rollout_and_episode_equal_stepping(dtype):
         assert torch.equal(out2[k], out3[k]), k
     assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.pos, e3.pos) and torch.equal(e1.vel, e3.vel) and torch.equal(e1.aux, e3.aux)
     assert torch.equal(e1.aux, e2.aux)
+
+
+def test_plugin_env_with_post_step_replays_the_reference():
+    """The single-world plugin (GPU step + mpe_observe callbacks + host post_step) through MultiAgentEnv
+    with post_step as post_step_callback, on an env of the fixture in which no treasure respawns."""
+    import mpe_hip
+    from mpe_hip.scenarios import load
+    g = load_golden(CASE)
+    sc = load(CASE + ".py").Scenario()
+    world = sc.make_world()
+    env = mpe_hip.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data, post_step_callback=sc.post_step)
+    assert env._scenario is None and [s.shape[0] for s in env.observation_space] == list(g["obs_dims"])
+    env.seed(0)
+    env.reset()
+    b = [k for k in range(g["pos0"].shape[0]) if g["alive0"][k].all() and g["alive"][:, k].all() and (g["holding0"][k] >= 0).any()][0]
+    A = env.n
+    for i, e in enumerate(world.entities):
+        e.state.p_pos = g["pos0"][b, i].copy()
+        if i < A:
+            e.state.p_vel = g["vel0"][b, i].copy()
+    for k, a in enumerate(world.agents[:6]):
+        a.holding = None if g["holding0"][b, k] < 0 else int(g["holding0"][b, k])
+    for l, t in enumerate(world.landmarks):
+        t.type, t.alive = int(g["ttype0"][b, l]), True
+    world.calculate_distances()
+    assert _close(np.concatenate([env._get_obs(a) for a in env.agents]), g["obs0"][b], 1e-9, 1e-12)
+    off = np.concatenate([[0], np.cumsum(g["obs_dims"])])
+    for t in range(25):
+        obs_n, rew_n, done, info = env.step([int(x) for x in g["actions"][t, b]])
+        for i in range(A):
+            assert obs_n[i].dtype == np.float32 and _close(obs_n[i], g["obs"][t, b, off[i]:off[i + 1]], 1e-9, 1e-12), (t, i)
+        assert _close(rew_n, g["rew"][t, b], 1e-9, 1e-12) and done is False
+        assert [tuple(x) for x in info["n"]] == [tuple(x) for x in g["info"][t, b]]
+        assert [-1 if a.holding is None else a.holding for a in world.agents[:6]] == list(g["holding"][t, b])
