@@ -283,11 +283,17 @@ __host__ __device__ inline int reset_stream_key(const RS& rs, unsigned long long
     return (int)r[w];
 }
 
+// Out-of-line generator block for the rarely taken draws of scenarios that respawn landmarks: a kernel
+// that tests several landmarks per step would otherwise carry one inlined copy of the ten rounds each.
+__device__ __noinline__ inline void philox_block_call(uint64_t key, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) {
+    Philox::block(key, ctr_lo, ctr_hi, out);
+}
+
 // n-th respawn position of world `b`, U(-lim, lim)^2, from the world's own stream key.  *spare
 // receives the low 5 bits of the block's first word, which the position does not use.
-__host__ __device__ inline V2<double> respawn_draw(int key, unsigned long long b, int n, double lim, int* spare = nullptr) {
+__device__ inline V2<double> respawn_draw(int key, unsigned long long b, int n, double lim, int* spare = nullptr) {
     uint32_t r[4];
-    Philox::block(0x5eed5eed00000000ull | (uint32_t)key, b, (unsigned long long)(uint32_t)n, r);
+    philox_block_call(0x5eed5eed00000000ull | (uint32_t)key, b, (unsigned long long)(uint32_t)n, r);
     if (spare) *spare = (int)(r[0] & 31u);
     V2<double> d;
     d.x = -lim + (lim + lim) * Philox::u01(r[0], r[1]);
