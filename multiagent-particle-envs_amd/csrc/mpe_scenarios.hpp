@@ -39,6 +39,10 @@ struct CfgBase {
     // tile of a chunk's width instead of the whole row), through observe_prepare / observe_chunk<C>
     static constexpr int OBS_CHUNKS = 1;
     static constexpr int CHUNK_MAX = 0;     // widest chunk; chunk c covers columns [chunk_offset(c), + chunk_width(c))
+    // OBS_LOOP: the chunks are produced by ONE copy of the code, observe_agent(i, ...), run in a loop over
+    // the agents with the wave's positions and velocities staged in LDS (Staged below) so that they can be
+    // indexed at run time; keeps a long per-agent observation routine out of the instruction stream A times
+    static constexpr bool OBS_LOOP = false;
     __host__ __device__ static constexpr bool movable(int) { return true; }    // Agent.movable
     __host__ __device__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
     // Entity whose magnitudes (size, mass, sensitivity, speed limit ...) entity e shares: a scenario whose
@@ -51,6 +55,23 @@ struct CfgBase {
     template <class RS> __host__ __device__ static int initial_aux(const RS&, unsigned long long, int) { return 0; }
     template <class RS, class Pos, class P> __host__ __device__ static void fix_reset(const RS&, unsigned long long, Pos&, const P&) {}
     template <class Pos, class P> __device__ static void post_step(Pos&, int*, const P&, unsigned long long) {}
+};
+
+// A wave's entity positions and agent velocities in LDS, one column per lane (value v of lane l at
+// v * 64 + l: conflict-free), for code that indexes entities at run time.
+template <typename T, int E, int A>
+struct Staged {
+    static constexpr int SIZE = (2 * E + 2 * A) * 64;
+    T* base;
+    int lane;
+    __device__ __forceinline__ V2<T> pos(int e) const { V2<T> v; v.x = base[(2 * e) * 64 + lane]; v.y = base[(2 * e + 1) * 64 + lane]; return v; }
+    __device__ __forceinline__ V2<T> vel(int i) const { V2<T> v; v.x = base[(2 * E + 2 * i) * 64 + lane]; v.y = base[(2 * E + 2 * i + 1) * 64 + lane]; return v; }
+    __device__ __forceinline__ void put(const V2<T> (&p)[E], const V2<T> (&w)[A]) const {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { base[(2 * e) * 64 + lane] = p[e].x; base[(2 * e + 1) * 64 + lane] = p[e].y; }
+#pragma unroll
+        for (int i = 0; i < A; ++i) { base[(2 * E + 2 * i) * 64 + lane] = w[i].x; base[(2 * E + 2 * i + 1) * 64 + lane] = w[i].y; }
+    }
 };
 
 // simple_spread casts its observation to float32 (simple_spread.py:130); the float64 kernel keeps
@@ -946,34 +967,35 @@ struct CollectorCfg : CfgBase {
     // sorted(zip(distance, index)): ascending distance, ties by index (collector.py:272-278)
     template <typename T> __device__ static __forceinline__ bool after(T ka, int ia, T kb, int ib) { return ka > kb || (ka == kb && ia > ib); }
 
-    // observation() of agent I, collector.py:268-295; cast to float32
-    template <typename T, int I>
-    __device__ static __forceinline__ void observe_chunk(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, int, T* row) {
+    static constexpr bool OBS_LOOP = true;
+
+    // observation() of agent i (a run-time index), collector.py:268-295; cast to float32
+    template <typename T>
+    __device__ static __forceinline__ void observe_agent(int i, const Staged<T, E, A>& w, const int* aux, T* row) {
         const int st = aux[0];
-        V2<T> me = pos[I];
-        asm volatile("" : "+v"(me.x), "+v"(me.y));      // keeps this chunk's arithmetic between its barriers
-        int k = 0;
-        row[k++] = round_f32(me.x); row[k++] = round_f32(me.y);
-        row[k++] = round_f32(vel[I].x); row[k++] = round_f32(vel[I].y);
-        if (I < NC) {
-            const int h = held(st, I);
-            row[k++] = (h == 0) ? T(1) : T(0); row[k++] = (h == 1) ? T(1) : T(0);
+        const V2<T> me = w.pos(i), mv = w.vel(i);
+        row[0] = round_f32(me.x); row[1] = round_f32(me.y);
+        row[2] = round_f32(mv.x); row[3] = round_f32(mv.y);
+        int k = 4;
+        if (i < NC) {
+            const int h = held(st, i);
+            row[4] = (h == 0) ? T(1) : T(0); row[5] = (h == 1) ? T(1) : T(0);
+            k = 6;
         }
         // ---- the 7 other agents, nearest first: offset, velocity, encoding (:257-266) ----
         {
             constexpr int N = A - 1;
             T key[N], dx[N], dy[N], vx[N], vy[N];
             int idx[N], code[N];        // code: 0 collector holding nothing, 1 / 2 holding type 0 / 1, 3 / 4 deposit of type 0 / 1
-            int n = 0;
 #pragma unroll
-            for (int j = 0; j < A; ++j) {
-                if (j == I) continue;
-                dx[n] = pos[j].x - me.x; dy[n] = pos[j].y - me.y;
+            for (int n = 0; n < N; ++n) {
+                const int j = n + (n >= i ? 1 : 0);
+                const V2<T> pj = w.pos(j), vj = w.vel(j);
+                dx[n] = pj.x - me.x; dy[n] = pj.y - me.y;
                 key[n] = norm2<T>(dx[n], dy[n]);
-                vx[n] = vel[j].x; vy[n] = vel[j].y;
+                vx[n] = vj.x; vy[n] = vj.y;
                 idx[n] = j;
                 code[n] = j < NC ? held(st, j) + 1 : 3 + (j - NC);
-                ++n;
             }
             auto ce = [&](int a, int b) {
                 const bool sw = after<T>(key[a], idx[a], key[b], idx[b]);
@@ -992,11 +1014,13 @@ struct CollectorCfg : CfgBase {
             ce(1, 2); ce(4, 6); ce(2, 3); ce(4, 5); ce(1, 2); ce(3, 4); ce(5, 6);
 #pragma unroll
             for (int q = 0; q < N; ++q) {
-                row[k++] = round_f32(dx[q]); row[k++] = round_f32(dy[q]);
-                row[k++] = round_f32(vx[q]); row[k++] = round_f32(vy[q]);
-                row[k++] = (code[q] == 3) ? T(1) : T(0); row[k++] = (code[q] == 4) ? T(1) : T(0);
-                row[k++] = (code[q] == 1) ? T(1) : T(0); row[k++] = (code[q] == 2) ? T(1) : T(0);
+                T* o = row + k + 8 * q;
+                o[0] = round_f32(dx[q]); o[1] = round_f32(dy[q]);
+                o[2] = round_f32(vx[q]); o[3] = round_f32(vy[q]);
+                o[4] = (code[q] == 3) ? T(1) : T(0); o[5] = (code[q] == 4) ? T(1) : T(0);
+                o[6] = (code[q] == 1) ? T(1) : T(0); o[7] = (code[q] == 2) ? T(1) : T(0);
             }
+            k += 8 * N;
         }
         // ---- the 6 treasures, nearest first: offset, type (:275-278,290-293) ----
         {
@@ -1004,7 +1028,8 @@ struct CollectorCfg : CfgBase {
             int idx[L], ty[L];
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                dx[l] = pos[A + l].x - me.x; dy[l] = pos[A + l].y - me.y;
+                const V2<T> pl = w.pos(A + l);
+                dx[l] = pl.x - me.x; dy[l] = pl.y - me.y;
                 key[l] = norm2<T>(dx[l], dy[l]);
                 idx[l] = l;
                 ty[l] = ttype(st, l);
@@ -1023,21 +1048,11 @@ struct CollectorCfg : CfgBase {
             ce(0, 5); ce(1, 3); ce(2, 4); ce(1, 2); ce(3, 4); ce(0, 3); ce(2, 5); ce(0, 1); ce(2, 3); ce(4, 5); ce(1, 2); ce(3, 4);
 #pragma unroll
             for (int q = 0; q < L; ++q) {
-                row[k++] = round_f32(dx[q]); row[k++] = round_f32(dy[q]);
-                row[k++] = (ty[q] == 0) ? T(1) : T(0); row[k++] = (ty[q] == 1) ? T(1) : T(0);
+                T* o = row + k + 4 * q;
+                o[0] = round_f32(dx[q]); o[1] = round_f32(dy[q]);
+                o[2] = (ty[q] == 0) ? T(1) : T(0); o[3] = (ty[q] == 1) ? T(1) : T(0);
             }
         }
-    }
-
-    template <typename T, int C>
-    __device__ static __forceinline__ void observe_all(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, T* row) {
-        observe_chunk<T, C>(pos, vel, aux, 0, row + chunk_offset(C));
-        if constexpr (C + 1 < A) observe_all<T, C + 1>(pos, vel, aux, row);
-    }
-
-    template <typename T, class P>
-    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, const P&, T* row) {
-        observe_all<T, 0>(pos, vel, aux, row);
     }
 
     // reward() :165-255 (everything is paid to collector 0) and benchmark_data() :132-155

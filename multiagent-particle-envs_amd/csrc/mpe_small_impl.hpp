@@ -122,6 +122,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     using IfTile = Tile<T, NF, true, EPW>;
     __shared__ __attribute__((aligned(16))) T tile_obs[ObsTile::SIZE];
     __shared__ __attribute__((aligned(16))) T tile_rew[RewTile::SIZE];
+    __shared__ T stage_lds[Cfg::OBS_LOOP ? Staged<T, E, A>::SIZE : 1];
     __shared__ __attribute__((aligned(16))) int tile_ii[INFO ? IiTile::SIZE : 4];
     __shared__ __attribute__((aligned(16))) T tile_if[INFO ? IfTile::SIZE : 4];
 
@@ -392,7 +393,29 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             if constexpr (Cfg::OBS_CHUNKS == 1) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
         }
         const long long row0 = (long long)t * B + env0;
-        if constexpr (Cfg::OBS_CHUNKS > 1)
+        if constexpr (Cfg::OBS_LOOP) {
+            // one copy of the per-agent observation code, looped over the agents; every lane reads back only
+            // the column of the staging area it wrote itself, so no barrier is needed before the first read
+            const bool active = EPW == 64 || lane < EPW;
+            const Staged<T, E, A> staged{stage_lds, lane};
+            if (active) staged.put(pos, vel);
+#pragma unroll 1
+            for (int i = 0; i < A; ++i) {
+                const int W = Cfg::chunk_width(i), S = Cfg::CHUNK_MAX;
+                if (active) Cfg::template observe_agent<T>(i, staged, aux, tile_obs + tile_lane * S);
+                __syncthreads();
+                T* gbase = obs_g + row0 * OT + Cfg::chunk_offset(i);
+                const int n = nvalid * W;
+                int r = lane / W, j = lane - r * W;        // W > 64: a stride of 64 crosses at most one row end
+#pragma unroll 4
+                for (int g = lane; g < n; g += 64) {
+                    gbase[(long long)r * OT + j] = tile_obs[r * S + j];
+                    j += 64;
+                    if (j >= W) { j -= W; ++r; }
+                }
+                __syncthreads();
+            }
+        } else if constexpr (Cfg::OBS_CHUNKS > 1)
             ObsChunks<T, Cfg, 0, EPW>::run(pos, vel, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_g + row0 * OT, lane, tile_lane,
                                            EPW == 64 || lane < EPW, nvalid);
         // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
