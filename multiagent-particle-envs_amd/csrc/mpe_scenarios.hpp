@@ -971,7 +971,7 @@ struct CollectorCfg : CfgBase {
 
     // observation() of agent i (a run-time index), collector.py:268-295; cast to float32
     template <typename T>
-    __device__ static __forceinline__ void observe_agent(int i, const Staged<T, E, A>& w, const int* aux, T* row) {
+    __device__ static __forceinline__ void observe_agent(int i, const Staged<T, E, A>& w, const int* aux, int, T* row) {
         const int st = aux[0];
         const V2<T> me = w.pos(i), mv = w.vel(i);
         row[0] = round_f32(me.x); row[1] = round_f32(me.y);

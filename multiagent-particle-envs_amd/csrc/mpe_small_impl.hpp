@@ -399,19 +399,20 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             const bool active = EPW == 64 || lane < EPW;
             const Staged<T, E, A> staged{stage_lds, lane};
             if (active) staged.put(pos, vel);
+            const auto ctx = Cfg::template observe_prepare<T>(pos, p);
 #pragma unroll 1
             for (int i = 0; i < A; ++i) {
                 const int W = Cfg::chunk_width(i), S = Cfg::CHUNK_MAX;
-                if (active) Cfg::template observe_agent<T>(i, staged, aux, tile_obs + tile_lane * S);
+                if (active) Cfg::template observe_agent<T>(i, staged, aux, ctx, tile_obs + tile_lane * S);
                 __syncthreads();
                 T* gbase = obs_g + row0 * OT + Cfg::chunk_offset(i);
                 const int n = nvalid * W;
-                int r = lane / W, j = lane - r * W;        // W > 64: a stride of 64 crosses at most one row end
+                int r = lane / W, j = lane - r * W;
 #pragma unroll 4
                 for (int g = lane; g < n; g += 64) {
                     gbase[(long long)r * OT + j] = tile_obs[r * S + j];
                     j += 64;
-                    if (j >= W) { j -= W; ++r; }
+                    while (j >= W) { j -= W; ++r; }
                 }
                 __syncthreads();
             }
