@@ -276,6 +276,27 @@ int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask
 int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* vel, void* comm,
                    mpe_stream_t stream);
 
+/*
+ * Generalised advantage estimation, the scan the reference's runner applies to a rollout before the
+ * policy update (multiagent/backup/runner_old.py:58-80), for all envs at once.  Needs no handle.
+ *   rewards, values  float[T][B][A]   what step returned / the value head predicted, per step
+ *   dones            uint8[T][B]      the done flag step t returned (mb_dones, runner_old.py:52-54)
+ *   last_values      float[B][A]      value of the observation after the last step (:64)
+ *   last_dones       uint8[B]         the env's current done flags (self.dones, :72); for a rollout that was
+ *                                     just collected this is dones[T-1]
+ *   adv, ret         float[T][B][A]   advantages and returns (mb_advs, mb_returns); ret = adv + values
+ * The runner's arrays are float32 (:61-62) and so are these; the scan runs in float64 as the runner's does.
+ * mode MPE_GAE_REFERENCE reproduces :69-80 as written: a single lastgaelam carried through the agent loop
+ * (agent i continues from agent i-1 of the same step, agent 0 from the last agent of step t+1) and the
+ * non-terminal mask of step t read from dones[t+1].  MPE_GAE_STANDARD scans every agent independently with
+ * the mask of step t read from dones[t].  All pointers are device pointers on `device`.
+ */
+#define MPE_GAE_REFERENCE 0
+#define MPE_GAE_STANDARD 1
+int mpe_gae(int device, int mode, int64_t n_envs, int32_t n_agents, int32_t n_steps, const float* rewards, const float* values,
+            const uint8_t* dones, const float* last_values, const uint8_t* last_dones, double gamma, double lam, float* adv,
+            float* ret, mpe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

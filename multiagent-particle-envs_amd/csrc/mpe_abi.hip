@@ -427,4 +427,19 @@ int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* 
     return MPE_OK;
 }
 
+int mpe_gae(int device, int mode, int64_t n_envs, int32_t n_agents, int32_t n_steps, const float* rewards, const float* values,
+            const uint8_t* dones, const float* last_values, const uint8_t* last_dones, double gamma, double lam, float* adv, float* ret,
+            mpe_stream_t stream) {
+    if (mode != MPE_GAE_REFERENCE && mode != MPE_GAE_STANDARD) return fail(nullptr, MPE_ERR_INVALID, "mpe_gae: unknown mode %d", mode);
+    if (n_envs <= 0 || n_agents < 1 || n_agents > MPE_MAX_AGENTS || n_steps < 1)
+        return fail(nullptr, MPE_ERR_INVALID, "mpe_gae: need n_envs > 0, 1..%d agents, n_steps > 0", MPE_MAX_AGENTS);
+    if (!rewards || !values || !dones || !last_values || !last_dones || !adv || !ret) return fail(nullptr, MPE_ERR_INVALID, "mpe_gae: NULL buffer");
+    if (adv == ret || (const float*)adv == values || (const float*)adv == rewards) return fail(nullptr, MPE_ERR_INVALID, "mpe_gae: adv must not alias another buffer");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+    e = launch_gae(mode, n_envs, n_agents, n_steps, rewards, values, dones, last_values, last_dones, gamma, lam, adv, ret, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "mpe_gae");
+    return MPE_OK;
+}
+
 }  // extern "C"

@@ -102,6 +102,10 @@ hipError_t launch_consensus(const HostSpec& s, long long n_envs, int dtype, int 
 hipError_t launch_consensus_reset(const HostSpec& s, long long n_envs, int dtype, unsigned long long seed, unsigned long long episode,
                                   const uint8_t* mask, void* pos, void* vel, void* hist, int32_t* aux, hipStream_t st);
 
+// advantage scan (mpe_gae.hip)
+hipError_t launch_gae(int mode, long long n_envs, int n_agents, int n_steps, const float* rew, const float* val, const uint8_t* dones,
+                      const float* last_val, const uint8_t* last_dones, double gamma, double lam, float* adv, float* ret, hipStream_t st);
+
 // wave-per-world kernels (mpe_wave.hip), env-major state; mode: 0 step, 1 rollout, 2 observe
 bool wave_supported(const HostSpec& s);
 hipError_t launch_wave(const HostSpec& s, const DevTable* table, long long n_envs, int dtype, int mode, const StepArgs& a, hipStream_t st);

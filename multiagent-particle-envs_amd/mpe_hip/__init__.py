@@ -6,3 +6,4 @@ from .batch import BatchedEnv  # noqa: F401
 from .world import Action, Agent, AgentState, Entity, EntityState, Landmark, Wall, World  # noqa: F401
 from .scenario import BaseScenario, HipScenario  # noqa: F401
 from .env import MultiAgentEnv, make_env  # noqa: F401
+from .train import BatchedVecEnv, gae  # noqa: F401

@@ -16,6 +16,7 @@ SCN_NONE, SCN_SPREAD, SCN_TAG, SCN_WORLD_COMM, SCN_SIMPLE, SCN_ADVERSARY, SCN_PU
 SCN_SPEAKER_LISTENER, SCN_REFERENCE, SCN_CRYPTO, SCN_PREDATOR_PREY, SCN_CONSENSUS = 7, 8, 9, 10, 11
 SCN_COLLECTOR = 12
 PHYSICS_CORE, PHYSICS_NEW_CORE = 0, 1
+GAE_REFERENCE, GAE_STANDARD = 0, 1
 MAX_AGENTS = 64
 MAX_LANDMARKS = 64
 MAX_WALLS = 16
@@ -70,6 +71,8 @@ EXPORTS = {
     # (handle, seed, episode, mask, pos, vel, comm, aux, stream)
     "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
+    # (device, mode, n_envs, n_agents, n_steps, rewards, values, dones, last_values, last_dones, gamma, lam, adv, ret, stream)
+    "mpe_gae": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 3),
 }
 
 _lib = None

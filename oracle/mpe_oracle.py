@@ -1253,3 +1253,51 @@ def collector_device_reset(spec: Spec, seed, episode, B):
     w = device_aux_words(seed, b, episode)
     ttype = ((w[:, 1, None].astype(np.int64) >> np.arange(6)) & 1)
     return pos, ttype, w[:, 0].astype(np.int32)
+
+
+# --------------------------------------------------------------------------
+# Generalised advantage estimation as the reference's runner computes it
+# (multiagent/backup/runner_old.py:58-80).
+# --------------------------------------------------------------------------
+def gae_reference(rewards, values, dones, last_values, last_dones, gamma, lam):
+    """runner_old.py:66-80 as written.  rewards / values float32 [T, B, A], dones bool [T, B] (the flag
+    step t returned), last_values float32 [B, A], last_dones bool [B] (the env's current flags).  One
+    `lastgaelam` runs through the agent loop, the mask of step t comes from dones[t+1], the scan is
+    float64 (1.0 - bool array) and the results are stored as float32.  Returns (advs, returns)."""
+    rewards = np.asarray(rewards, np.float32)
+    values = np.asarray(values, np.float32)
+    T, B, A = rewards.shape
+    advs = np.zeros_like(rewards)
+    rets = np.zeros_like(rewards)
+    lastgaelam = 0
+    for t in reversed(range(T)):
+        for i in range(A):
+            if t == T - 1:
+                nextnonterminal = 1.0 - np.asarray(last_dones)
+                nextvalues = np.asarray(last_values, np.float32)[:, i]
+            else:
+                nextnonterminal = 1.0 - np.asarray(dones[t + 1])
+                nextvalues = values[t + 1][:, i]
+            delta = rewards[t][:, i] + gamma * nextvalues * nextnonterminal - values[t][:, i]
+            advs[t][:, i] = lastgaelam = delta + gamma * lam * nextnonterminal * lastgaelam
+            rets[t][:, i] = advs[t][:, i] + values[t][:, i]
+    return advs, rets
+
+
+def gae_standard(rewards, values, dones, last_values, gamma, lam):
+    """Per-agent scan with the mask of step t taken from dones[t] (the flag returned with that step's
+    reward); same float32 inputs / float64 scan / float32 outputs."""
+    rewards = np.asarray(rewards, np.float32)
+    values = np.asarray(values, np.float32)
+    T, B, A = rewards.shape
+    advs = np.zeros_like(rewards)
+    rets = np.zeros_like(rewards)
+    last = np.zeros((B, A))
+    for t in reversed(range(T)):
+        nnt = (1.0 - np.asarray(dones[t]))[:, None]
+        nv = np.asarray(last_values, np.float32) if t == T - 1 else values[t + 1]
+        delta = rewards[t] + (np.float32(gamma) * nv) * nnt - values[t]
+        last = delta + gamma * lam * nnt * last
+        advs[t] = last
+        rets[t] = advs[t] + values[t]
+    return advs, rets

@@ -276,3 +276,24 @@ def test_oracle_reproduces_collector():
         assert np.array_equal(holding, g["holding"][t]) and np.array_equal(ttype, g["ttype"][t]) and np.array_equal(alive, g["alive"][t]), t
         assert np.array_equal(pos[:, A:], g["treasure_pos"][t]), t
     assert (~g["alive"]).sum() > 5 and (g["holding"] >= 0).sum() > 100 and g["info"][..., 2].sum() > 10
+
+
+def test_oracle_reproduces_reference_gae():
+    """Advantages / returns of the reference's own Runner.run (runner_old.py:58-80), bit for bit."""
+    g = load_golden("gae")
+    advs, rets = orc.gae_reference(g["rewards"], g["values"], g["dones"], g["last_values"], g["last_dones"], float(g["gamma"]), float(g["lam"]))
+    assert advs.dtype == np.float32 and np.array_equal(advs, g["advs"]) and np.array_equal(rets, g["returns"])
+    # the per-agent scan differs from it (the runner chains its accumulator through the agents)
+    a2, _ = orc.gae_standard(g["rewards"], g["values"], g["dones"], g["last_values"], float(g["gamma"]), float(g["lam"]))
+    assert np.abs(a2 - advs).max() > 0.1
+    # and reduces to the textbook recursion for one agent without episode ends
+    r, v = g["rewards"][:, :, :1], g["values"][:, :, :1]
+    a1, _ = orc.gae_standard(r, v, np.zeros_like(g["dones"]), g["last_values"][:, :1], 0.9, 0.8)
+    nxt = np.concatenate([v[1:], g["last_values"][None, :, :1]], axis=0).astype(np.float64)
+    delta = r + 0.9 * nxt - v
+    want = np.zeros_like(delta)
+    acc = 0.0
+    for t in reversed(range(r.shape[0])):
+        acc = delta[t] + 0.9 * 0.8 * acc
+        want[t] = acc
+    assert np.allclose(a1, want, rtol=1e-5, atol=1e-5)

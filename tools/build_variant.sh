@@ -8,7 +8,7 @@ mkdir -p ../../variants
 obj=/tmp/variant_$name.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c $src -o $obj
 objs=""
-for o in mpe_small_f32 mpe_small_f64 mpe_small mpe_wave mpe_consensus mpe_reset mpe_abi; do
+for o in mpe_small_f32 mpe_small_f64 mpe_small mpe_wave mpe_consensus mpe_gae mpe_reset mpe_abi; do
   if [ "$o.hip" = "$src" ]; then objs="$objs $obj"; else objs="$objs build/$o.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libmpe_$name.so $objs

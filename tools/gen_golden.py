@@ -917,6 +917,58 @@ def run_collector(ref, seed=20240661, B=32):
     return pos0, vel0, actions, rec
 
 
+def run_gae(ref, seed=20240671):
+    """Advantages and returns from the reference's own Runner.run (multiagent/backup/runner_old.py:39-80,
+    the nenv > 1 branch): the runner is driven with a scripted env and model that replay fixed rewards,
+    values and done flags, so the fixture holds exactly what its scan computes."""
+    runner_mod = _load("ref_runner_old", os.path.join(REF, "multiagent", "backup", "runner_old.py"))
+    rng = np.random.RandomState(seed)
+    T, B, A = 25, 48, 3
+    rewards = rng.uniform(-2, 1, (T, B, A)).astype(np.float32)
+    values = rng.uniform(-3, 3, (T, B, A)).astype(np.float32)
+    last_values = rng.uniform(-3, 3, (B, A)).astype(np.float32)
+    dones = rng.uniform(size=(T, B)) < 0.08
+    dones[T - 1, ::5] = True
+    gamma, lam = 0.99, 0.95
+
+    class Env:
+        num_envs = B
+
+        def __init__(self):
+            self.t = 0
+
+        def reset(self):
+            return np.zeros((B, A, 1), np.float32)
+
+        def step(self, actions):
+            t = self.t
+            self.t += 1
+            return np.zeros((B, A, 1), np.float32), rewards[t], dones[t].copy(), {}
+
+    class Model:
+        def __init__(self):
+            self.t = 0
+
+        def step(self, obs, nenv):
+            t = self.t
+            self.t += 1
+            return np.zeros((B, A), np.int64), values[t]
+
+        def value(self, obs, nenv):
+            return last_values
+
+        def share_actions(self, mb_actions):
+            return mb_actions
+
+    world = types.SimpleNamespace(n=A)
+    runner = runner_mod.Runner(env=Env(), world=world, model=Model(), nsteps=T, gamma=gamma, lam=lam)
+    mb_obs, mb_actions, mb_rewards, mb_values, mb_advs, mb_returns, mb_dones = runner.run()
+    unpack = lambda per_agent: np.stack([np.asarray(x).reshape(T, B) for x in per_agent], axis=2)
+    assert np.array_equal(unpack(mb_rewards), rewards) and np.array_equal(unpack(mb_values), values)
+    return dict(rewards=rewards, values=values, dones=dones, last_values=last_values, last_dones=dones[T - 1].copy(),
+                gamma=np.array(gamma), lam=np.array(lam), advs=unpack(mb_advs).astype(np.float32), returns=unpack(mb_returns).astype(np.float32))
+
+
 def known_answers(ref):
     """Anchors that do not use state injection."""
     out = {}
@@ -1016,6 +1068,8 @@ def main():
         np.savez_compressed(path, scenario=np.array(scn), pos0=pos0, vel0=vel0,
                             actions=actions.astype(np.int32), **rec)
         print("wrote", path, os.path.getsize(path), "bytes")
+    np.savez_compressed(os.path.join(OUT, "gae.npz"), **run_gae(ref))
+    print("wrote gae.npz")
     walls = run_walls(ref)
     np.savez_compressed(os.path.join(OUT, "walls.npz"), **walls)
     print("wrote walls.npz")
