@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (a one-GPU box cannot host the real N > 1 run)")
+    ap.add_argument("--episodes-per-launch", type=int, default=1,
+                    help="rollout mode: consecutive episodes (each with its own on-device reset) per mpe_episodes launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-mode", action="store_true")
     ap.add_argument("--event-every", type=int, default=4,
@@ -126,10 +128,11 @@ def main():
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
-    actions = torch.randint(0, 5, (EPISODE, B, n_act), generator=gen, device=dev, dtype=torch.int32)
+    K = max(1, args.episodes_per_launch) if args.mode == "rollout" else 1
+    actions = torch.randint(0, 5, (K * EPISODE, B, n_act), generator=gen, device=dev, dtype=torch.int32)
     for col, n in enumerate(env.action_dims):        # comm words are uniform over dim_c
         if n != 5:
-            actions[:, :, col] = torch.randint(0, n, (EPISODE, B), generator=gen, device=dev, dtype=torch.int32)
+            actions[:, :, col] = torch.randint(0, n, (K * EPISODE, B), generator=gen, device=dev, dtype=torch.int32)
     out = None
     pairs = []                                  # (start, end, steps) events around dominant-kernel launches
     graphs = {}
@@ -156,20 +159,24 @@ def main():
         open_pair = None
         while done_steps < n_steps:
             n = min(EPISODE, n_steps - done_steps)
+            k_ep = 1
+            if mode == "rollout" and K > 1 and n == EPISODE:
+                k_ep = max(1, min(K, (n_steps - done_steps) // EPISODE))
+                n = k_ep * EPISODE
             if mode != "rollout":
                 env.reset(seed=1234 + first_env)
             if mode == "rollout":
                 # one event pair brackets EVENT_GROUP consecutive launches (an event pair costs
                 # about 7 us on the stream, a tenth of one launch), every event_every-th group
                 grp = launches // EVENT_GROUP
-                rec = record and n == EPISODE and (grp % args.event_every == 0)
+                rec = record and n == K * EPISODE and (grp % args.event_every == 0)
                 if rec and launches % EVENT_GROUP == 0:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record()
                     open_pair = e0
                 # mpe_episode: on-device reset of every env + n steps in one launch
                 out = env.rollout(actions[:n], out if (out is not None and out["obs"].shape[0] == n) else None,
-                                  reset_seed=1234 + first_env)
+                                  reset_seed=1234 + first_env, episodes=k_ep)
                 if rec and launches % EVENT_GROUP == EVENT_GROUP - 1 and open_pair is not None:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
@@ -220,18 +227,20 @@ def main():
 
     run(args.warmup, args.mode, False)
     elapsed, launches = timed(args.steps, args.mode, True)
-    steps_per_launch = EPISODE if args.mode == "rollout" else 1
+    steps_per_launch = K * EPISODE if args.mode == "rollout" else 1
     # average duration of one dominant-kernel launch and the env steps it covers (a graph replay
     # holds EPISODE single-step launches, so its time is divided by the steps it ran)
     tot_ms = sum(a.elapsed_time(b) for a, b, _ in pairs)
     if args.mode == "rollout":
-        kern_ms, avg_steps = tot_ms / max(1, len(pairs) * EVENT_GROUP), float(EPISODE)
+        kern_ms, avg_steps = tot_ms / max(1, len(pairs) * EVENT_GROUP), float(K * EPISODE)
     else:
         kern_ms, avg_steps = tot_ms / max(1, sum(n for _, _, n in pairs)), 1.0
 
     s = 4 if args.dtype == "f32" else 8
     lo = env.layout
-    bytes_env_step = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, steps_per_launch, reads_state=args.mode != "rollout")
+    # an episode's state write-back is once per launch; every episode of a launch is counted as if it wrote it
+    bytes_env_step = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, EPISODE if args.mode == "rollout" else 1,
+                                       reads_state=args.mode != "rollout")
     bytes_launch = bytes_env_step * B * avg_steps
     achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
 
@@ -252,7 +261,7 @@ def main():
 
     # optional statistics all-reduce (RCCL), outside every timed region: return of agent 0 over the last episode
     stats = EpisodeStats(dev)
-    stats.add_episode(out["rew"] if out is not None else env.rew)
+    stats.add_episode(out["rew"][-EPISODE:] if out is not None else env.rew)
     tot = stats.reduce()
     mean_rew0 = tot["return_agent0"] / max(1.0, tot["episodes"])
 
@@ -279,7 +288,8 @@ def main():
             "config": {"workload": "%s A=%d L=%d, %d envs/GPU, %d-step episodes, uniform random int actions, on-device reset each episode"
                                    % (args.scenario, A, env.n_landmarks, B, EPISODE),
                        "envs_per_gpu": B, "global_envs": world * B, "episode_steps": EPISODE,
-                       "launch": {"rollout": "mpe_episode (on-device reset + %d steps) per launch" % EPISODE, "step": "mpe_step, 1 step/launch, eager",
+                       "launch": {"rollout": ("mpe_episode (on-device reset + %d steps) per launch" % EPISODE) if K == 1 else
+                                             ("mpe_episodes: %d x (on-device reset + %d steps) per launch" % (K, EPISODE)), "step": "mpe_step, 1 step/launch, eager",
                                   "graph": "mpe_step, 1 step/launch, %d launches per hipGraph replay" % EPISODE}[args.mode],
                        "parallelism": "env-index shards, no data-path collective"},
             "env_steps_per_s": value / A,

@@ -242,6 +242,19 @@ int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* ac
                 void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done, int32_t* info_i,
                 void* info_f, int32_t n_steps, mpe_stream_t stream);
 
+/*
+ * n_episodes consecutive episodes in one launch: as mpe_episode(h, seed, first_episode + k, ...) for k = 0 ..
+ * n_episodes - 1, each of steps_per_episode steps; the step axis of actions and outputs has
+ * n_episodes * steps_per_episode entries, episode after episode.  What the benchmark loop "reset, 25 random
+ * steps, repeat" issues, without a launch boundary between the episodes (a launch starts with draws and
+ * action fetches during which nothing is stored, and ends with a tail of late waves; inside one launch the
+ * waves drift apart and fill both).  Scenarios of the in-register kernels only (MpeLayout.state_env_major
+ * == 0, not consensus): MPE_ERR_UNSUPPORTED otherwise unless n_episodes == 1.
+ */
+int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_episodes, int32_t steps_per_episode,
+                 const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done,
+                 int32_t* info_i, void* info_f, mpe_stream_t stream);
+
 /* The scenario callbacks on the current state, without stepping: observation for every agent
  * (what MultiAgentEnv.reset returns, environment.py:122-127) and, when rew is not NULL, also
  * reward (environment.py:149-152) and benchmark_data (info_i / info_f, NULL to skip). */

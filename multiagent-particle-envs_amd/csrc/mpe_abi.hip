@@ -389,6 +389,20 @@ int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* ac
     return run(h, 1, a, stream, "mpe_episode");
 }
 
+int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_episodes, int32_t steps_per_episode, const int32_t* actions,
+                 void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f,
+                 mpe_stream_t stream) {
+    if (!h) return MPE_ERR_INVALID;
+    if (n_episodes < 1 || steps_per_episode < 1) return fail(h, MPE_ERR_INVALID, "mpe_episodes: n_episodes and steps_per_episode must be >= 1");
+    if ((long long)n_episodes * steps_per_episode > 0x7fffffffLL) return fail(h, MPE_ERR_INVALID, "mpe_episodes: too many steps");
+    if (n_episodes > 1 && (h->use_wave || h->spec.scenario == MPE_SCN_CONSENSUS))
+        return fail(h, MPE_ERR_UNSUPPORTED, "mpe_episodes: this scenario's kernel runs one episode per launch");
+    StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_episodes * steps_per_episode};
+    a.aux = aux;
+    a.reset = ResetArgs{1, seed, first_episode, landmark_limit(h->spec), n_episodes > 1 ? steps_per_episode : 0};
+    return run(h, 1, a, stream, "mpe_episodes");
+}
+
 int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm, const int32_t* aux, void* obs, void* rew,
                 int32_t* info_i, void* info_f, mpe_stream_t stream) {
     if (h && !rew && (info_i || info_f)) return fail(h, MPE_ERR_INVALID, "mpe_observe: info_i / info_f require rew");

@@ -54,6 +54,7 @@ struct ResetArgs {
     int enabled;
     unsigned long long seed, episode;
     double landmark_lim;      // landmarks ~ U(-lim, lim)^2; agents always U(-1, 1)^2
+    int period;               // > 0: the launch holds several episodes, reset again every `period` steps (episode + 1, + 2, ...)
 };
 
 // Episode bookkeeping of mpe_step_auto (all pointers NULL = plain mpe_step).

@@ -243,12 +243,42 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     }
     constexpr bool want_info = INFO;
 
-    for (int t0 = 0; t0 < n_steps; t0 += NP * CH) {
+    int to_reset = (MODE == MODE_ROLLOUT && rs.enabled && rs.period > 0) ? rs.period : 0x7fffffff;     // steps until the next episode starts
+    unsigned long long episode = rs.episode;
+    for (int t0 = 0; t0 < n_steps;) {
       if (MODE != MODE_OBSERVE) {
           if (t0 > 0) load_actions(t0);
+          if (MODE == MODE_ROLLOUT && to_reset == 0) {
+              // next episode of a multi-episode launch: Scenario.reset_world again, while the action words arrive
+              episode += 1;
+              to_reset = rs.period;
+              ResetArgs nr = rs;
+              nr.episode = episode;
+              draw_world(nr);
+#pragma unroll
+              for (int i = 0; i < A; ++i) { vel[i].x = T(0); vel[i].y = T(0); }
+              if (NC > 0) {
+#pragma unroll
+                  for (int c = 0; c < NC; ++c) comm[c] = T(0);
+              }
+#pragma unroll
+              for (int k = 0; k < NX; ++k) {
+                  aux[k] = Cfg::DYNAMIC ? Cfg::initial_aux(nr, (unsigned long long)b, k) : reset_aux(nr, (unsigned long long)b, k, Cfg::L);
+                  if (valid) aux_g[(long long)k * B + b] = aux[k];
+              }
+              if (valid) {
+#pragma unroll
+                  for (int e = A; e < E; ++e) {
+                      pos_g[(long long)(2 * e) * B + b] = pos[e].x;
+                      pos_g[(long long)(2 * e + 1) * B + b] = pos[e].y;
+                  }
+              }
+          }
           pack_actions();
       }
-      const int nc = (n_steps - t0 < NP * CH) ? n_steps - t0 : NP * CH;
+      int nc = (n_steps - t0 < NP * CH) ? n_steps - t0 : NP * CH;
+      nc = nc < to_reset ? nc : to_reset;       // a chunk of fetched actions ends with its episode
+      to_reset = (to_reset == 0x7fffffff) ? to_reset : to_reset - nc;
       if (t0 == 0) STAMP(1);
       unsigned __int128 packed = 0;
       for (int kc = 0; kc < nc; ++kc) {
@@ -452,6 +482,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             __syncthreads();   // tiles are rewritten by the next step
         }
       }
+      t0 += nc;
     }
 
     STAMP(60);

@@ -161,11 +161,12 @@ class BatchedEnv:
                                                    p["info_i"], p["info_f"], self._stream()))
         return self.obs, self.rew, self.done, (self.info_i, self.info_f)
 
-    def rollout(self, actions, out=None, reset_seed=None):
+    def rollout(self, actions, out=None, reset_seed=None, episodes=1):
         """``T`` steps in one launch for pre-computed actions ``[T, B, n_act]``.  Returns a dict of
         ``[T, ...]`` tensors (pass the previous result as ``out`` to reuse its buffers).  With
         ``reset_seed`` every env is first reset on device inside the same launch (one episode per
-        launch, like ``reset(seed, observe=False)`` followed by ``rollout``)."""
+        launch, like ``reset(seed, observe=False)`` followed by ``rollout``); with ``episodes`` = K > 1
+        the T steps are K consecutive episodes of T / K steps, each starting with its own reset."""
         T = int(actions.shape[0])
         a = self._actions(actions, (T,))
         lo, B = self.layout, self.n_envs
@@ -179,6 +180,13 @@ class BatchedEnv:
             _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["aux"], _ptr(out["obs"]),
                                                       _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]), _ptr(out["info_f"]), T,
                                                       self._stream()))
+        elif episodes > 1:
+            if T % episodes:
+                raise ValueError("%d steps do not split into %d episodes" % (T, episodes))
+            _lib.check(self._h, self._lib.mpe_episodes(self._h, int(reset_seed), self._episode, int(episodes), T // episodes, _ptr(a), p["pos"],
+                                                       p["vel"], p["comm"], p["aux"], _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]),
+                                                       _ptr(out["info_i"]), _ptr(out["info_f"]), self._stream()))
+            self._episode += int(episodes)
         else:
             _lib.check(self._h, self._lib.mpe_episode(self._h, int(reset_seed), self._episode, _ptr(a), p["pos"], p["vel"], p["comm"],
                                                       p["aux"], _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]),

@@ -114,3 +114,41 @@ def test_reset_is_reproducible_and_independent_of_batch_size():
     assert torch.equal(a.pos, a2.pos)
     a2.reset(seed=4, observe=False)
     assert not torch.equal(a.pos, a2.pos)
+
+
+@pytest.mark.parametrize("scenario,dtype", [("simple_spread", "float32"), ("simple_spread", "float64"), ("simple_tag", "float32"),
+                                            ("simple_world_comm", "float32"), ("simple_reference", "float64"),
+                                            ("simple_predator_prey", "float32"), ("collector", "float64")])
+def test_multi_episode_launch_equals_single_episode_launches(scenario, dtype):
+    """mpe_episodes(K) == K mpe_episode launches with consecutive episode numbers, bit for bit; B is not a
+    multiple of the wave size for half of the cases."""
+    import mpe_hip
+    dt = getattr(torch, dtype)
+    B = 4096 if dtype == "float32" else 1000
+    K, T = 3, 25
+    e1 = mpe_hip.BatchedEnv(scenario, B, dtype=dt, device="cuda:0", info=True)
+    e2 = mpe_hip.BatchedEnv(scenario, B, dtype=dt, device="cuda:0", info=True)
+    gen = torch.Generator("cuda:0").manual_seed(7)
+    a = torch.stack([torch.randint(0, n, (K * T, B), dtype=torch.int32, device="cuda:0", generator=gen) for n in e1.action_dims], dim=2).contiguous()
+    e1._episode = e2._episode = 5
+    out = e1.rollout(a, reset_seed=13, episodes=K)
+    assert e1._episode == 5 + K
+    for k in range(K):
+        o = e2.rollout(a[k * T:(k + 1) * T].contiguous(), reset_seed=13)
+        for key in ("obs", "rew", "done", "info_i", "info_f"):
+            if o[key] is not None:
+                assert torch.equal(out[key][k * T:(k + 1) * T], o[key]), (scenario, k, key)
+    assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.vel, e2.vel)
+    if e1.aux is not None:
+        assert torch.equal(e1.aux, e2.aux)
+    if e1.comm is not None:
+        assert torch.equal(e1.comm, e2.comm)
+
+
+def test_multi_episode_launch_is_refused_where_unsupported():
+    import mpe_hip
+    for scenario, kw in (("consensus", {}), ("simple_spread", dict(n_agents=5, n_landmarks=5))):
+        env = mpe_hip.BatchedEnv(scenario, 128, device="cuda:0", **kw)
+        a = torch.zeros(50, 128, env.n_act, dtype=torch.int32, device="cuda:0")
+        with pytest.raises(mpe_hip.MpeError):
+            env.rollout(a, reset_seed=1, episodes=2)
