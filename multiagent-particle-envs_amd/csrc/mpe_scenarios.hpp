@@ -38,7 +38,7 @@ struct CfgBase {
     // > 1: the observation row is produced and streamed out in this many equal column chunks (one LDS
     // tile of a chunk's width instead of the whole row), through observe_prepare / observe_chunk<C>
     static constexpr int OBS_CHUNKS = 1;
-    static constexpr int CHUNK_MAX = 0;     // widest chunk; chunk c covers columns [chunk_offset(c), + chunk_width(c))
+    static constexpr int CHUNK_MAX = 0, CHUNK_MIN = 0;     // widest / narrowest chunk; chunk c covers columns [chunk_offset(c), + chunk_width(c))
     // OBS_LOOP: the chunks are produced by ONE copy of the code, observe_agent(i, ...), run in a loop over
     // the agents with the wave's positions and velocities staged in LDS (Staged below) so that they can be
     // indexed at run time; keeps a long per-agent observation routine out of the instruction stream A times
@@ -950,7 +950,7 @@ struct CollectorCfg : CfgBase {
     static constexpr int OBS_TOTAL = NC * OBS_COL + (A - NC) * OBS_DEP;
     static constexpr int NI = 3 * A + 1, NF = 0, N_AUX = 3;       // info: (collected, deposited, collisions) per agent, the state word
     static constexpr bool DYNAMIC = true, NEW_CORE = true;
-    static constexpr int OBS_CHUNKS = A, CHUNK_MAX = OBS_COL;
+    static constexpr int OBS_CHUNKS = A, CHUNK_MAX = OBS_COL, CHUNK_MIN = OBS_DEP;
     __host__ __device__ static constexpr int chunk_width(int c) { return c < NC ? OBS_COL : OBS_DEP; }
     __host__ __device__ static constexpr int chunk_offset(int c) { return c < NC ? c * OBS_COL : NC * OBS_COL + (c - NC) * OBS_DEP; }
     __host__ __device__ static constexpr bool collides(int e) { return e < A; }       // :40,57

@@ -437,12 +437,13 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 __syncthreads();
                 T* gbase = obs_g + row0 * OT + Cfg::chunk_offset(i);
                 const int n = nvalid * W;
-                int r = lane / W, j = lane - r * W;
+                static_assert(!Cfg::OBS_LOOP || Cfg::CHUNK_MIN > 64, "the flush below assumes a 64-value stride crosses at most one row end");
+                int r = 0, j = lane;
 #pragma unroll 4
                 for (int g = lane; g < n; g += 64) {
                     gbase[(long long)r * OT + j] = tile_obs[r * S + j];
                     j += 64;
-                    while (j >= W) { j -= W; ++r; }
+                    if (j >= W) { j -= W; ++r; }
                 }
                 __syncthreads();
             }
