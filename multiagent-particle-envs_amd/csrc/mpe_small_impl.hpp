@@ -26,8 +26,9 @@ enum { MODE_STEP = 0, MODE_ROLLOUT = 1, MODE_OBSERVE = 2 };
 //   contiguous 64*W-element block of the global array, which goes out as 16-byte vectors with no
 //   index arithmetic.  Row writes then land with lane stride W: fine when W*sizeof(V)/4 is not a
 //   multiple of a large power of two (simple_spread 42, simple_tag 62: 2-way, free for ds_write).
-// PADDED: row stride W|1 (odd) keeps both directions conflict-free for any W (simple_world_comm:
-//   192 values per row would otherwise be a 32-way conflict) at the price of a divide per element.
+// PADDED: row stride W|1 (odd) keeps the row writes conflict-free for any W (simple_world_comm: 192 values
+//   per row would otherwise be a 32-way conflict); full tiles still leave as 16-byte vectors, each gathered
+//   from four padded LDS words (4 % fewer cycles than dword stores at 262 144 worlds).
 template <typename V, int W, bool LINEAR, int ROWS>
 struct Tile {
     static constexpr int STRIDE = LINEAR ? W : (W | 1);
@@ -49,6 +50,19 @@ struct Tile {
 #pragma unroll
             for (int it = 0; it < FULL_IT; ++it) dst[it * 64 + lane] = src[it * 64 + lane];
             if (REM > 0 && lane < REM) dst[FULL_IT * 64 + lane] = src[FULL_IT * 64 + lane];
+        } else if (!LINEAR && FULL && W % VEC == 0) {
+            // padded rows, 16-byte stores: vector g covers values [VEC * (g % NVR), + VEC) of row g / NVR
+            typedef V VT __attribute__((ext_vector_type(VEC)));
+            constexpr int NVR = W / VEC, NV = ROWS * NVR;
+#pragma unroll
+            for (int it = 0; it < (NV + 63) / 64; ++it) {
+                const int g = it * 64 + lane;
+                const int r = g / NVR, j = (g - r * NVR) * VEC;
+                VT v;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) v[q] = tile[r * STRIDE + j + q];
+                if (NV % 64 == 0 || g < NV) *reinterpret_cast<VT*>(gdst + r * W + j) = v;
+            }
         } else {
             const int n = nvalid * W;
 #pragma unroll
