@@ -236,6 +236,8 @@ def main():
     else:
         kern_ms, avg_steps = tot_ms / max(1, sum(n for _, _, n in pairs)), 1.0
 
+    if not pairs or kern_ms <= 0.0:          # too few launches for an event group: fall back to the wall clock
+        kern_ms = elapsed * 1e3 / max(1, launches)
     s = 4 if args.dtype == "f32" else 8
     lo = env.layout
     # an episode's state write-back is once per launch; every episode of a launch is counted as if it wrote it
