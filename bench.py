@@ -21,7 +21,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   roofline      HBM roofline of the dominant kernel; achieved = algorithmic bytes per launch /
                 average launch duration from HIP event pairs inside the timed region, each
                 bracketing 4 consecutive launches (every 4th group by default, --event-every)
-  cpu_baseline  the single-env numpy oracle (oracle/mpe_oracle.py) timed on this host, 1 core
+  cpu_baseline  the single-env numpy oracle (oracle/mpe_oracle.py) timed on this host, 1 core; its
+                "n_process" entry is the same loop in --cpu-procs processes, one env each
   step_mode     the same workload issued as one mpe_step launch per step (hipGraph), for comparison
 """
 import argparse
@@ -76,7 +77,43 @@ def cpu_baseline(seconds=12.0):
             "sample": "%d episodes x %d steps of one simple_spread env (3 agents), numpy oracle, %.1f s" % (episodes, EPISODE, el)}
 
 
+def _cpu_worker(seconds):
+    """One process of the N-process CPU figure: prints "<env steps> <seconds>"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import mpe_oracle as orc
+    spec = orc.spec_spread()
+    rng = np.random.RandomState(os.getpid())
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        pos, vel, _ = orc.reset(spec, rng, 1)
+        for t in range(EPISODE):
+            pos, vel, *_ = orc.env_step(spec, pos, vel, rng.randint(0, 5, (1, 3)))
+        steps += EPISODE
+    print(steps, time.perf_counter() - t0)
+
+
+def cpu_baseline_processes(n_procs, seconds=6.0):
+    """The same loop as cpu_baseline, one env per process in n_procs fresh Python processes (no GPU use)."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds)],
+                              stdout=subprocess.PIPE, env=env) for _ in range(n_procs)]
+    steps, longest = 0, 0.0
+    for p in procs:
+        o, _ = p.communicate(timeout=seconds * 10 + 120)
+        if p.returncode != 0:
+            return None
+        n, el = o.split()
+        steps, longest = steps + int(n), max(longest, float(el))
+    return {"value": steps * 3 / longest, "unit": "agent-steps/s", "cores": n_procs,
+            "sample": "%d processes x one simple_spread env, %.1f s each" % (n_procs, seconds)}
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(float(sys.argv[2]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2500)
@@ -93,6 +130,8 @@ def main():
     ap.add_argument("--episodes-per-launch", type=int, default=1,
                     help="rollout mode: consecutive episodes (each with its own on-device reset) per mpe_episodes launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=min(16, os.cpu_count() or 1),
+                    help="processes of the N-process CPU figure (0 = skip); a one-GPU box's CPU share is 16")
     ap.add_argument("--no-step-mode", action="store_true")
     ap.add_argument("--event-every", type=int, default=4,
                     help="time every k-th group of 4 episode launches with one HIP event pair (a pair costs ~7 us on the "
@@ -280,6 +319,8 @@ def main():
 
     if rank == 0:
         cpu = None if args.no_cpu_baseline else cpu_baseline()
+        if cpu is not None and args.cpu_procs > 1:
+            cpu["n_process"] = cpu_baseline_processes(args.cpu_procs)
         value = world * B * A * args.steps / elapsed
         line = {
             "metric": "agent-steps/sec (whole node) batched simple_spread N=3" if args.scenario == "simple_spread" and A == 3

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Profile bench.py with rocprofv3 on the GPU box and summarise the result.
 
-Three separate runs (counters are never combined with tracing, and FETCH_SIZE / WRITE_SIZE do not
+Four separate runs (counters are never combined with tracing, and FETCH_SIZE / WRITE_SIZE do not
 fit one pass):
   1. rocprofv3 --kernel-trace --stats      -> per-kernel call counts and average durations
   2. rocprofv3 --pmc FETCH_SIZE            -> bytes read from beyond L2, per dispatch
   3. rocprofv3 --pmc WRITE_SIZE            -> bytes written beyond L2, per dispatch
+  4. rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+                                           -> VALU instructions per wave and the share of a wave's lifetime spent issuing them
 
 Writes into <out>/ :  kernel_stats.csv (copy of pass 1's table), bench.json (the line bench.py
 printed under pass 1) and traffic.json, keyed like bench.py's lookup
@@ -93,6 +95,29 @@ def main():
     }}
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print(json.dumps(traffic))
+
+    # 4. VALU utilisation of the dominant kernel (its own pass: 5 SQ counters + 1 GRBM counter)
+    names = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+    d = os.path.join(out, "valu")
+    rc = run(["rocprofv3", "--pmc"] + names + ["--output-format", "csv", "-d", d, "--"] + short, os.path.join(out, "valu.log"), 200)
+    print("VALU pass rc", rc)
+    if rc != 0:
+        sys.exit(rc)
+    acc = {n: [] for n in names}
+    for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] in acc and kern in r["Kernel_Name"] and mode_re.search(r["Kernel_Name"]):
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    avg = {n: (sum(v) / len(v) if v else None) for n, v in acc.items()}
+    valu = {key: dict(avg, dispatches=len(acc["SQ_WAVES"]))}
+    if avg["SQ_WAVES"] and avg["SQ_WAVE_CYCLES"]:
+        # SQ_WAVE_CYCLES and SQ_ACTIVE_INST_VALU count in units of four cycles, summed over waves
+        valu[key]["valu_insts_per_wave"] = avg["SQ_INSTS_VALU"] / avg["SQ_WAVES"]
+        valu[key]["valu_issue_fraction_of_wave_lifetime"] = avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_WAVE_CYCLES"]
+        valu[key]["cycles_per_valu_inst_while_issuing"] = 4.0 * avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_INSTS_VALU"]
+        valu[key]["mean_wave_lifetime_cycles"] = 4.0 * avg["SQ_WAVE_CYCLES"] / avg["SQ_WAVES"]
+    json.dump(valu, open(os.path.join(out, "valu.json"), "w"), indent=1)
+    print(json.dumps(valu))
 
 
 if __name__ == "__main__":
