@@ -36,6 +36,21 @@ static int hip_fail(MpeHandle* h, hipError_t e, const char* what) {
     return fail(h, MPE_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
+// Makes `device` current for the launches of one entry point and puts the caller's device back on return.
+struct DeviceScope {
+    int prev = -1;
+    hipError_t status;
+    explicit DeviceScope(int device) {
+        status = hipGetDevice(&prev);
+        if (status != hipSuccess) { prev = -1; return; }
+        if (prev != device) status = hipSetDevice(device);
+        else prev = -1;
+    }
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 // The specialised kernels fix a scenario's structure at compile time; refuse a spec that
 // disagrees with it instead of silently simulating something else.
 static const char* check_structure(const HostSpec& s) {
@@ -237,7 +252,7 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     const bool new_core_scn = spec->scenario == MPE_SCN_PREDATOR_PREY || spec->scenario == MPE_SCN_CONSENSUS || spec->scenario == MPE_SCN_COLLECTOR;
     if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE && !new_core_scn) {
         delete h;
-        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey and consensus only");
+        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey, consensus and collector only");
     }
     if (new_core_scn && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: this scenario runs on the new_core physics"); }
     if (s.physics == MPE_PHYSICS_NEW_CORE && !spec->accel) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: new_core physics needs the accel array"); }
@@ -260,7 +275,7 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
     s.n_walls = spec->n_walls;
     if (s.n_walls < 0 || s.n_walls > MPE_MAX_WALLS) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: 0..%d walls (got %d)", MPE_MAX_WALLS, spec->n_walls); }
     if (s.n_walls > 0) {
-        if (spec->scenario != MPE_SCN_NONE && !new_core_scn) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: walls are simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey and consensus only"); }
+        if (spec->scenario != MPE_SCN_NONE && !new_core_scn) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: walls are simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey, consensus and collector only"); }
         if (!spec->wall_vertical || !spec->wall_axis_pos || !spec->wall_end0 || !spec->wall_end1 || !spec->wall_width || !spec->wall_hard) {
             delete h;
             return fail(nullptr, MPE_ERR_INVALID, "mpe_create: a wall array is NULL");
@@ -300,7 +315,8 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
             t.wall_vertical[w] = s.wall_vertical[w]; t.wall_hard[w] = s.wall_hard[w]; t.wall_axis_pos[w] = s.wall_axis_pos[w];
             t.wall_end0[w] = s.wall_end0[w]; t.wall_end1[w] = s.wall_end1[w]; t.wall_width[w] = s.wall_width[w];
         }
-        if ((e = hipSetDevice(device)) != hipSuccess || (e = hipMalloc((void**)&h->table, sizeof(DevTable))) != hipSuccess ||
+        DeviceScope scope(device);
+        if ((e = scope.status) != hipSuccess || (e = hipMalloc((void**)&h->table, sizeof(DevTable))) != hipSuccess ||
             (e = hipMemcpy(h->table, &t, sizeof(DevTable), hipMemcpyHostToDevice)) != hipSuccess) {
             if (h->table) (void)hipFree(h->table);
             delete h;
@@ -313,7 +329,7 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
 
 int mpe_destroy(MpeHandle* h) {
     if (h && h->table) {
-        (void)hipSetDevice(h->device);
+        DeviceScope scope(h->device);
         (void)hipFree(h->table);
     }
     delete h;
@@ -342,10 +358,11 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
     if (a.info_i && h->layout.n_info_i == 0) return fail(h, MPE_ERR_INVALID, "%s: this scenario has no benchmark_data; info_i must be NULL", who);
     if (h->layout.n_aux > 0 && !a.aux) return fail(h, MPE_ERR_INVALID, "%s: aux must not be NULL for a scenario with a goal landmark", who);
     // rows leave the kernels as 16-byte vectors
-    const void* bufs[] = {a.pos, a.vel, a.comm, a.obs, a.rew, a.info_i, a.info_f, a.actions, a.aux};
+    const void* bufs[] = {a.pos, a.vel, a.comm, a.obs, a.rew, a.done, a.info_i, a.info_f, a.actions, a.aux};
     for (const void* ptr : bufs)
         if (((uintptr_t)ptr & 15u) != 0) return fail(h, MPE_ERR_INVALID, "%s: every buffer must be 16-byte aligned (got %p)", who, ptr);
-    hipError_t e = hipSetDevice(h->device);
+    DeviceScope scope(h->device);
+    hipError_t e = scope.status;
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
     e = h->spec.scenario == MPE_SCN_CONSENSUS ? launch_consensus(h->spec, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream)
         : h->use_wave                           ? launch_wave(h->spec, h->table, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream)
@@ -419,7 +436,8 @@ int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask
     if ((comm_rows > 0 || h->layout.n_hist_rows > 0) && !comm)
         return fail(h, MPE_ERR_INVALID, "mpe_reset: comm must not be NULL for a scenario with speaking agents or a history");
     if (h->layout.n_aux > 0 && !aux) return fail(h, MPE_ERR_INVALID, "mpe_reset: aux must not be NULL for a scenario with a goal landmark");
-    hipError_t e = hipSetDevice(h->device);
+    DeviceScope scope(h->device);
+    hipError_t e = scope.status;
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
     e = h->spec.scenario == MPE_SCN_CONSENSUS
             ? launch_consensus_reset(h->spec, h->layout.n_envs, h->dtype, seed, episode, mask, pos, vel, comm, aux, (hipStream_t)stream)
@@ -434,7 +452,8 @@ int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* 
     if (!u || !pos || !vel) return fail(h, MPE_ERR_INVALID, "mpe_world_step: u, pos and vel must not be NULL");
     const int rows = h->layout.n_speakers * h->spec.dim_c;
     if (rows > 0 && (!c || !comm)) return fail(h, MPE_ERR_INVALID, "mpe_world_step: c and comm must not be NULL for a world with speaking agents");
-    hipError_t e = hipSetDevice(h->device);
+    DeviceScope scope(h->device);
+    hipError_t e = scope.status;
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
     e = launch_world_step(h->spec, h->table, h->layout.n_envs, h->dtype, u, c, pos, vel, comm, rows, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, "mpe_world_step");
@@ -449,7 +468,8 @@ int mpe_gae(int device, int mode, int64_t n_envs, int32_t n_agents, int32_t n_st
         return fail(nullptr, MPE_ERR_INVALID, "mpe_gae: need n_envs > 0, 1..%d agents, n_steps > 0", MPE_MAX_AGENTS);
     if (!rewards || !values || !dones || !last_values || !last_dones || !adv || !ret) return fail(nullptr, MPE_ERR_INVALID, "mpe_gae: NULL buffer");
     if (adv == ret || (const float*)adv == values || (const float*)adv == rewards) return fail(nullptr, MPE_ERR_INVALID, "mpe_gae: adv must not alias another buffer");
-    hipError_t e = hipSetDevice(device);
+    DeviceScope scope(device);
+    hipError_t e = scope.status;
     if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
     e = launch_gae(mode, n_envs, n_agents, n_steps, rewards, values, dones, last_values, last_dones, gamma, lam, adv, ret, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(nullptr, e, "mpe_gae");

@@ -257,43 +257,86 @@ struct WorldCommCfg : CfgBase {
         return (i1 && o1) || (i2 && o2) || (!i1 && !o1 && !i2 && !o2) || leader(i);
     }
 
-    // observation(), simple_world_comm.py:224-287
+    // The 192-value row leaves in two halves of 96 columns (three full 128-byte lines of a float32 row each)
+    // through a tile of half the size: a 64 x 193 float32 tile is 49 KB of LDS, which leaves room for three
+    // of these one-wave workgroups per CU, one short of its four SIMDs.
+    static constexpr int OBS_CHUNKS = 2, CHUNK_MAX = OBS_TOTAL / 2, CHUNK_MIN = OBS_TOTAL / 2;
+    __host__ __device__ static constexpr int chunk_width(int) { return OBS_TOTAL / 2; }
+    __host__ __device__ static constexpr int chunk_offset(int c) { return c * (OBS_TOTAL / 2); }
+    __host__ __device__ static constexpr int obs_offset(int i) { return i < N_ADV ? i * OBS_ADV : N_ADV * OBS_ADV + (i - N_ADV) * OBS_GOOD; }
+
+    // in_forest bits of every agent (bit 2i+f), shared by the chunks of one step's observation
     template <typename T, class P>
-    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const int*, const P& p, T* row) {
+    __device__ static __forceinline__ int observe_prepare(const V2<T> (&pos)[E], const P& p) {
         bool inf[A][2];
         forest_bits<T>(pos, p, inf);
+        int bits = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) bits |= (inf[i][0] ? 1 : 0) << (2 * i) | (inf[i][1] ? 1 : 0) << (2 * i + 1);
+        return bits;
+    }
+
+    // observation(), simple_world_comm.py:224-287: columns [LO, HI) of the world's row, written to row[0 .. HI - LO).
+    // Every column index is a constant once the loops are unrolled, so values outside the window cost nothing.
+    template <typename T, int LO, int HI>
+    __device__ static __forceinline__ void observe_cols(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, int forest, T* row) {
+        bool inf[A][2];
+#pragma unroll
+        for (int i = 0; i < A; ++i) { inf[i][0] = (forest >> (2 * i)) & 1; inf[i][1] = (forest >> (2 * i + 1)) & 1; }
         int k = 0;
+        auto put = [&](T v) {
+            if (k >= LO && k < HI) row[k - LO] = v;
+            ++k;
+        };
 #pragma unroll
         for (int i = 0; i < A; ++i) {
-            row[k++] = vel[i].x; row[k++] = vel[i].y;
-            row[k++] = pos[i].x; row[k++] = pos[i].y;
+            V2<T> me = pos[i];
+            // A chunk is computed between the barriers that bracket its tile; pinning the agent's position keeps
+            // the compiler from hoisting the second chunk's arithmetic (96 live values) above the first.
+            // (float32 only: the float64 parity build does not need it, and a 64-bit operand pinned this way was
+            // seen to come back corrupted in the instantiation that spills most.)
+            if constexpr (sizeof(T) == 4)
+                if (HI - LO < OBS_TOTAL && obs_offset(i) < HI && obs_offset(i) + (adversary(i) ? OBS_ADV : OBS_GOOD) > LO)
+                    asm volatile("" : "+v"(me.x), "+v"(me.y));
+            put(vel[i].x); put(vel[i].y);
+            put(me.x); put(me.y);
 #pragma unroll
-            for (int l = 0; l < L; ++l) { row[k++] = pos[A + l].x - pos[i].x; row[k++] = pos[A + l].y - pos[i].y; }
+            for (int l = 0; l < L; ++l) { put(pos[A + l].x - me.x); put(pos[A + l].y - me.y); }
 #pragma unroll
             for (int j = 0; j < A; ++j) {
                 if (j == i) continue;
                 const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
-                row[k++] = vis ? pos[j].x - pos[i].x : T(0);
-                row[k++] = vis ? pos[j].y - pos[i].y : T(0);
+                put(vis ? pos[j].x - me.x : T(0));
+                put(vis ? pos[j].y - me.y : T(0));
             }
             if (!adversary(i)) {   // good agents put in_forest before other_vel (:287)
-                row[k++] = inf[i][0] ? T(1) : T(-1);
-                row[k++] = inf[i][1] ? T(1) : T(-1);
+                put(inf[i][0] ? T(1) : T(-1));
+                put(inf[i][1] ? T(1) : T(-1));
             }
 #pragma unroll
             for (int j = 0; j < A; ++j) {
                 if (j == i || adversary(j)) continue;
                 const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
-                row[k++] = vis ? vel[j].x : T(0);
-                row[k++] = vis ? vel[j].y : T(0);
+                put(vis ? vel[j].x : T(0));
+                put(vis ? vel[j].y : T(0));
             }
             if (adversary(i)) {    // :281-285
-                row[k++] = inf[i][0] ? T(1) : T(-1);
-                row[k++] = inf[i][1] ? T(1) : T(-1);
+                put(inf[i][0] ? T(1) : T(-1));
+                put(inf[i][1] ? T(1) : T(-1));
 #pragma unroll
-                for (int c = 0; c < DIM_C; ++c) row[k++] = comm[c];
+                for (int c = 0; c < DIM_C; ++c) put(comm[c]);
             }
         }
+    }
+
+    template <typename T, int C>
+    __device__ static __forceinline__ void observe_chunk(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const int*, int forest, T* row) {
+        observe_cols<T, C * (OBS_TOTAL / 2), (C + 1) * (OBS_TOTAL / 2)>(pos, vel, comm, forest, row);
+    }
+
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const int*, const P& p, T* row) {
+        observe_cols<T, 0, OBS_TOTAL>(pos, vel, comm, observe_prepare<T>(pos, p), row);
     }
 
     // reward() :142-198 and benchmark_data() :115-123; info also carries the integer masks.
@@ -741,7 +784,9 @@ struct PredatorPreyCfg : CfgBase {
             // A chunk is computed between the barriers that bracket its tile; pinning the agent's own position
             // here keeps the compiler from hoisting every chunk's arithmetic (315 live values) above the first.
             V2<T> me = pos[i];
-            if (I1 - I0 == 1) asm volatile("" : "+v"(me.x), "+v"(me.y));
+            // (float32 only, see simple_world_comm's observe_cols)
+            if constexpr (sizeof(T) == 4)
+                if (I1 - I0 == 1) asm volatile("" : "+v"(me.x), "+v"(me.y));
             row[k++] = round_f32(vel[i].x); row[k++] = round_f32(vel[i].y);
             row[k++] = round_f32(me.x); row[k++] = round_f32(me.y);
             if (member(i)) row[k++] = holds(flags, i) ? T(1) : T(-1);
@@ -773,7 +818,7 @@ struct PredatorPreyCfg : CfgBase {
     }
 
     template <typename T, int C>
-    __device__ static __forceinline__ void observe_chunk(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, int forest, T* row) {
+    __device__ static __forceinline__ void observe_chunk(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, int forest, T* row) {
         observe_agents<T, C, C + 1>(pos, vel, aux, forest, row);
     }
 

@@ -81,25 +81,50 @@ struct Tile {
 
 // Observation rows of a scenario that produces them in OBS_CHUNKS column chunks: every chunk is
 // written into the wave's (rows x chunk width) tile and streamed to its columns of the env-major
-// block at gbase (row stride OT), 4 bytes per lane.
-template <typename T, class Cfg, int C, int EPW>
+// block at gbase (row stride OT).  The tile's row stride is the widest chunk, made odd when that
+// width would put every lane's row on the same few LDS banks; chunks of such a tile whose width is
+// a whole number of 16-byte vectors leave as vectors, the others 4 bytes per lane.
+template <typename T, class Cfg>
+struct ChunkTile {
+    static constexpr bool LINEAR = ((Cfg::CHUNK_MAX * (int)sizeof(T) / 4) % 16) != 0;
+    static constexpr int STRIDE = LINEAR ? Cfg::CHUNK_MAX : (Cfg::CHUNK_MAX | 1);
+};
+
+template <typename T, class Cfg, int C, int EPW, bool FULL>
 struct ObsChunks {
-    static constexpr int W = Cfg::chunk_width(C), S = Cfg::CHUNK_MAX, COL0 = Cfg::chunk_offset(C);
+    static constexpr int W = Cfg::chunk_width(C), S = ChunkTile<T, Cfg>::STRIDE, COL0 = Cfg::chunk_offset(C);
+    static constexpr int VEC = 16 / (int)sizeof(T);
+    static constexpr bool VECTORS = FULL && EPW == 64 && !ChunkTile<T, Cfg>::LINEAR && W % VEC == 0 && COL0 % VEC == 0 && Cfg::OBS_TOTAL % VEC == 0;
     template <class Pos, class Vel, class Ctx>
-    static __device__ __forceinline__ void run(const Pos& pos, const Vel& vel, const int* aux, const Ctx& ctx, T* tile, T* gbase, int lane,
-                                               int tile_lane, bool active, int nvalid) {
-        if (active) Cfg::template observe_chunk<T, C>(pos, vel, aux, ctx, tile + tile_lane * S);
+    static __device__ __forceinline__ void run(const Pos& pos, const Vel& vel, const T* comm, const int* aux, const Ctx& ctx, T* tile, T* gbase,
+                                               int lane, int tile_lane, bool active, int nvalid) {
+        if (active) Cfg::template observe_chunk<T, C>(pos, vel, comm, aux, ctx, tile + tile_lane * S);
         __syncthreads();
-        const int n = nvalid * W;
+        if constexpr (VECTORS) {
+            // vector g covers values [VEC * (g % NVR), + VEC) of row g / NVR, gathered from the padded tile
+            typedef T VT __attribute__((ext_vector_type(VEC)));
+            constexpr int NVR = W / VEC, NV = EPW * NVR;
 #pragma unroll
-        for (int it = 0; it < (EPW * W + 63) / 64; ++it) {
-            const int g = it * 64 + lane;
-            const int r = g / W;
-            if (g < n) gbase[(long long)r * Cfg::OBS_TOTAL + COL0 + (g - r * W)] = tile[r * S + (g - r * W)];
+            for (int it = 0; it < (NV + 63) / 64; ++it) {
+                const int g = it * 64 + lane;
+                const int r = g / NVR, j = (g - r * NVR) * VEC;
+                VT v;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) v[q] = tile[r * S + j + q];
+                if (NV % 64 == 0 || g < NV) *reinterpret_cast<VT*>(gbase + (long long)r * Cfg::OBS_TOTAL + COL0 + j) = v;
+            }
+        } else {
+            const int n = nvalid * W;
+#pragma unroll
+            for (int it = 0; it < (EPW * W + 63) / 64; ++it) {
+                const int g = it * 64 + lane;
+                const int r = g / W;
+                if (g < n) gbase[(long long)r * Cfg::OBS_TOTAL + COL0 + (g - r * W)] = tile[r * S + (g - r * W)];
+            }
         }
         __syncthreads();
         if constexpr (C + 1 < Cfg::OBS_CHUNKS)
-            ObsChunks<T, Cfg, C + 1, EPW>::run(pos, vel, aux, ctx, tile, gbase, lane, tile_lane, active, nvalid);
+            ObsChunks<T, Cfg, C + 1, EPW, FULL>::run(pos, vel, comm, aux, ctx, tile, gbase, lane, tile_lane, active, nvalid);
     }
 };
 
@@ -129,7 +154,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     constexpr int NI = Cfg::NI > 0 ? Cfg::NI : 1, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C, NX = Cfg::N_AUX;
     constexpr int NC = Cfg::S * Cfg::DIM_C;      // comm state values: the speakers' utterances in agent order
     constexpr int OW = Cfg::OBS_CHUNKS > 1 ? Cfg::CHUNK_MAX : OT;        // columns held by the observation tile
-    constexpr bool LIN = Cfg::OBS_CHUNKS > 1 || ((OW * (int)sizeof(T) / 4) % 16) != 0;
+    constexpr bool LIN = ((OW * (int)sizeof(T) / 4) % 16) != 0;
     using ObsTile = Tile<T, OW, LIN, EPW>;
     using RewTile = Tile<T, A, true, EPW>;
     using IiTile = Tile<int, NI, true, EPW>;
@@ -446,7 +471,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             const auto ctx = Cfg::template observe_prepare<T>(pos, p);
 #pragma unroll 1
             for (int i = 0; i < A; ++i) {
-                const int W = Cfg::chunk_width(i), S = Cfg::CHUNK_MAX;
+                const int W = Cfg::chunk_width(i), S = ChunkTile<T, Cfg>::STRIDE;
                 if (active) Cfg::template observe_agent<T>(i, staged, aux, ctx, tile_obs + tile_lane * S);
                 __syncthreads();
                 T* gbase = obs_g + row0 * OT + Cfg::chunk_offset(i);
@@ -462,8 +487,8 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 __syncthreads();
             }
         } else if constexpr (Cfg::OBS_CHUNKS > 1)
-            ObsChunks<T, Cfg, 0, EPW>::run(pos, vel, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_g + row0 * OT, lane, tile_lane,
-                                           EPW == 64 || lane < EPW, nvalid);
+            ObsChunks<T, Cfg, 0, EPW, FULL>::run(pos, vel, comm, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_g + row0 * OT, lane,
+                                                 tile_lane, EPW == 64 || lane < EPW, nvalid);
         // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
         // reset starts its episode untouched
         if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, (unsigned long long)b);

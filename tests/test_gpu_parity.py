@@ -521,3 +521,19 @@ def test_misaligned_buffer_is_refused():
                       env.rew.data_ptr(), env.done.data_ptr(), None, None, None)
     assert rc == -1
     assert b"16-byte aligned" in lib.mpe_last_error(env._h)
+    odd_done = torch.zeros(64 + 2, dtype=torch.uint8, device="cuda")[2:]      # rollouts zero the flags as dwords
+    rc = lib.mpe_step(env._h, actions.data_ptr(), env.pos.data_ptr(), env.vel.data_ptr(), None, None, env.obs.data_ptr(),
+                      env.rew.data_ptr(), odd_done.data_ptr(), None, None, None)
+    assert rc == -1
+    assert b"16-byte aligned" in lib.mpe_last_error(env._h)
+
+
+def test_entry_points_leave_the_callers_device_current():
+    """The library selects the handle's device for its launches and puts the caller's device back."""
+    import mpe_hip
+    env = mpe_hip.BatchedEnv("simple_spread", 64, dtype=torch.float32)
+    before = torch.cuda.current_device()
+    env.reset(seed=1)
+    env.step(torch.zeros(64, 3, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == before
