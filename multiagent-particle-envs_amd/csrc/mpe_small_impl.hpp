@@ -26,9 +26,9 @@ enum { MODE_STEP = 0, MODE_ROLLOUT = 1, MODE_OBSERVE = 2 };
 //   contiguous 64*W-element block of the global array, which goes out as 16-byte vectors with no
 //   index arithmetic.  Row writes then land with lane stride W: fine when W*sizeof(V)/4 is not a
 //   multiple of a large power of two (simple_spread 42, simple_tag 62: 2-way, free for ds_write).
-// PADDED: row stride W|1 (odd) keeps the row writes conflict-free for any W (simple_world_comm: 192 values
-//   per row would otherwise be a 32-way conflict); full tiles still leave as 16-byte vectors, each gathered
-//   from four padded LDS words (4 % fewer cycles than dword stores at 262 144 worlds).
+// PADDED: row stride W|1 (odd) keeps the row writes conflict-free for any W (a row of 96 or 192 values
+//   would otherwise be a 32-way conflict); full tiles still leave as 16-byte vectors, each gathered from
+//   four padded LDS words (4 % fewer cycles than dword stores for simple_world_comm at 262 144 worlds).
 template <typename V, int W, bool LINEAR, int ROWS>
 struct Tile {
     static constexpr int STRIDE = LINEAR ? W : (W | 1);

@@ -57,7 +57,7 @@ def main():
     bench = ["python3", "bench.py", "--no-cpu-baseline", "--scenario", args.scenario, "--envs", str(args.envs),
              "--dtype", args.dtype, "--mode", args.mode] + [a for a in extra if a != "--"]
     # small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>: MODE 1 = rollout, 0 = step
-    mode_re = re.compile(r">, (?:true|false), %s, (?:true|false), (?:true|false), \d+>\(" % {"rollout": "1", "step": "0", "graph": "0"}[args.mode])
+    mode_re = re.compile(r"(?:>|Cfg), (?:true|false), %s, (?:true|false), (?:true|false), \d+>\(" % {"rollout": "1", "step": "0", "graph": "0"}[args.mode])
     kern = args.kernel or "small_kernel<%s" % ("float" if args.dtype == "f32" else "double")
 
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(out, "stats"), "--"] + bench,
