@@ -32,7 +32,7 @@ struct ConsensusParams {
     T size, mass, sens, force_scale;        // uniform over the agents (mpe_create checks)
     T dt, one_minus_damping, contact_force, contact_margin;
     T wall_axis_pos[CW], wall_end0[CW], wall_end1[CW], wall_width[CW];
-    unsigned char wall_vertical[CW], wall_hard[CW];
+    int wall_vertical[CW], wall_hard[CW];          // dwords: scalar loads cannot fetch single bytes of the kernel arguments
     int ghost;
     long long n_envs;
 };

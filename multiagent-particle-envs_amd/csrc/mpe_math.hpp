@@ -110,10 +110,20 @@ __device__ __forceinline__ bool wall_force(V2<T> p, T size, bool ghost, bool ver
 // wall's ends, theta = 0 (core.py:299-302) -- is evaluated inline without trigonometry
 // (cos(0) * mag = mag, sin(0) * |mag| = 0 * |mag|); an entity sticking out past an end takes the
 // out-of-line general routine, so the kernel carries one copy of it instead of one per pair.
+// The result travels back in registers: a reference parameter of an out-of-line function is a scratch-memory
+// slot, and reading it back makes the caller wait for every older memory operation of the wave, the previous
+// step's output stores included.
+template <typename T> struct WallHit { T x, y; int hit; };
+
 template <typename T>
-__device__ __noinline__ bool wall_force_past_end(V2<T> p, T size, bool ghost, bool vertical, bool hard, T axis_pos, T end0, T end1, T width,
-                                                 T cf, T k, V2<T>& out) {
-    return wall_force<T>(p, size, ghost, vertical, hard, axis_pos, end0, end1, width, cf, k, out);
+__device__ __noinline__ WallHit<T> wall_force_past_end(V2<T> p, T size, bool ghost, bool vertical, bool hard, T axis_pos, T end0, T end1, T width,
+                                                       T cf, T k) {
+    V2<T> f;
+    f.x = T(0); f.y = T(0);
+    WallHit<T> r;
+    r.hit = wall_force<T>(p, size, ghost, vertical, hard, axis_pos, end0, end1, width, cf, k, f) ? 1 : 0;
+    r.x = f.x; r.y = f.y;
+    return r;
 }
 
 template <typename T>
@@ -122,7 +132,11 @@ __device__ __forceinline__ bool wall_force_fast(V2<T> p, T size, bool ghost, boo
     if (ghost && !hard) return false;
     const T prll = vertical ? p.y : p.x, perp = vertical ? p.x : p.y;
     if (prll < end0 - size || prll > end1 + size) return false;
-    if (prll < end0 || prll > end1) return wall_force_past_end<T>(p, size, ghost, vertical, hard, axis_pos, end0, end1, width, cf, k, out);
+    if (prll < end0 || prll > end1) {
+        const WallHit<T> r = wall_force_past_end<T>(p, size, ghost, vertical, hard, axis_pos, end0, end1, width, cf, k);
+        out.x = r.x; out.y = r.y;
+        return r.hit != 0;
+    }
     const T dist_min = size + T(0.5) * width;
     const T delta = perp - axis_pos;
     const T dist = t_abs<T>(delta);
@@ -285,19 +299,23 @@ __host__ __device__ inline int reset_stream_key(const RS& rs, unsigned long long
 
 // Out-of-line generator block for the rarely taken draws of scenarios that respawn landmarks: a kernel
 // that tests several landmarks per step would otherwise carry one inlined copy of the ten rounds each.
-__device__ __noinline__ inline void philox_block_call(uint64_t key, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) {
+// (the block comes back in registers: a reference parameter of an out-of-line function is a scratch-memory slot,
+// and reading it back waits for every older memory operation of the wave)
+struct PhiloxWords { uint32_t w0, w1, w2, w3; };
+__device__ __noinline__ inline PhiloxWords philox_block_call(uint64_t key, uint64_t ctr_lo, uint64_t ctr_hi) {
+    uint32_t out[4];
     Philox::block(key, ctr_lo, ctr_hi, out);
+    return PhiloxWords{out[0], out[1], out[2], out[3]};
 }
 
 // n-th respawn position of world `b`, U(-lim, lim)^2, from the world's own stream key.  *spare
 // receives the low 5 bits of the block's first word, which the position does not use.
 __device__ inline V2<double> respawn_draw(int key, unsigned long long b, int n, double lim, int* spare = nullptr) {
-    uint32_t r[4];
-    philox_block_call(0x5eed5eed00000000ull | (uint32_t)key, b, (unsigned long long)(uint32_t)n, r);
-    if (spare) *spare = (int)(r[0] & 31u);
+    const PhiloxWords r = philox_block_call(0x5eed5eed00000000ull | (uint32_t)key, b, (unsigned long long)(uint32_t)n);
+    if (spare) *spare = (int)(r.w0 & 31u);
     V2<double> d;
-    d.x = -lim + (lim + lim) * Philox::u01(r[0], r[1]);
-    d.y = -lim + (lim + lim) * Philox::u01(r[2], r[3]);
+    d.x = -lim + (lim + lim) * Philox::u01(r.w0, r.w1);
+    d.y = -lim + (lim + lim) * Philox::u01(r.w2, r.w3);
     return d;
 }
 

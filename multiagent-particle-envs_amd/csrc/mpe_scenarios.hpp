@@ -23,11 +23,13 @@ struct SmallParams {
     // read by scenarios on the new_core physics with walls only
     T force_scale[A];                           // mass (* accel): new_core.py:214
     T wall_axis_pos[SMALL_MAX_WALLS], wall_end0[SMALL_MAX_WALLS], wall_end1[SMALL_MAX_WALLS], wall_width[SMALL_MAX_WALLS];
-    unsigned char wall_vertical[SMALL_MAX_WALLS], wall_hard[SMALL_MAX_WALLS], ghost[A];
+    int wall_vertical[SMALL_MAX_WALLS], wall_hard[SMALL_MAX_WALLS], ghost[A];      // dwords: scalar loads cannot fetch single bytes of the kernel arguments
     double size_d[E];                           // float64 sizes for the reset's placement test
 };
 
-// Defaults of a scenario description; a scenario overrides what differs.
+// Defaults of a scenario description; a scenario overrides what differs.  The constexpr helpers are force-inlined:
+// left to the inliner's budget, rep() was seen compiled as a real call in the largest kernel, which turned every
+// p.mass[rep(i)] into a run-time indexed vector load of the kernel arguments (and a wait for the wave's older stores).
 struct CfgBase {
     static constexpr int BITS = 3;          // bits kept of every action int (moves 0..4, comm words 0..dim_c-1)
     static constexpr bool SHARED = false;   // World.collaborative: step returns the summed reward to every agent
@@ -37,20 +39,32 @@ struct CfgBase {
     static constexpr int N_WALLS = 0;
     // > 1: the observation row is produced and streamed out in this many equal column chunks (one LDS
     // tile of a chunk's width instead of the whole row), through observe_prepare / observe_chunk<C>
+    // the instruction scheduler does not move code across the boundaries between the step's phases (contacts |
+    // walls | integration | reward | observation); for kernels whose straight-line step is thousands of
+    // instructions this bounds the values live at once
+#ifdef MPE_FENCES
+    static constexpr bool PHASE_FENCES = true;
+#else
+    static constexpr bool PHASE_FENCES = false;
+#endif
     static constexpr int OBS_CHUNKS = 1;
     static constexpr int CHUNK_MAX = 0, CHUNK_MIN = 0;     // widest / narrowest chunk; chunk c covers columns [chunk_offset(c), + chunk_width(c))
     // OBS_LOOP: the chunks are produced by ONE copy of the code, observe_agent(i, ...), run in a loop over
     // the agents with the wave's positions and velocities staged in LDS (Staged below) so that they can be
     // indexed at run time; keeps a long per-agent observation routine out of the instruction stream A times
     static constexpr bool OBS_LOOP = false;
-    __host__ __device__ static constexpr bool movable(int) { return true; }    // Agent.movable
-    __host__ __device__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
+    // OBS_ROW_PASSES = R > 0: the observation is evaluated R times per step through observe_pass(..., row, mine);
+    // in pass k the lanes of worlds [k * 64 / R, (k + 1) * 64 / R) write their whole rows into a tile of 64 / R
+    // rows, which leaves as contiguous 16-byte vectors (for rows too long to hold 64 of them in LDS)
+    static constexpr int OBS_ROW_PASSES = 0;
+    __host__ __device__ __forceinline__ static constexpr bool movable(int) { return true; }    // Agent.movable
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
     // Entity whose magnitudes (size, mass, sensitivity, speed limit ...) entity e shares: a scenario whose
     // roles have uniform properties names one representative per role, so that the kernel reads a handful
     // of parameters instead of one set per entity (mpe_create checks that the spec is uniform per role).
-    __host__ __device__ static constexpr int rep(int e) { return e; }
+    __host__ __device__ __forceinline__ static constexpr int rep(int e) { return e; }
     // envs per wave: fewer when a 64-row observation tile does not fit the LDS
-    template <typename T> __host__ __device__ static constexpr int epw() { return 64; }
+    template <typename T> __host__ __device__ __forceinline__ static constexpr int epw() { return 64; }
     // hooks of scenarios with DYNAMIC state
     template <class RS> __host__ __device__ static int initial_aux(const RS&, unsigned long long, int) { return 0; }
     template <class RS, class Pos, class P> __host__ __device__ static void fix_reset(const RS&, unsigned long long, Pos&, const P&) {}
@@ -91,8 +105,8 @@ struct SpreadCfg : CfgBase {
     static constexpr int NI = A_ + 1;   // collisions per agent, occupied_landmarks
     static constexpr int NF = A_ + 1;   // min_dists, benchmark reward per agent
     // landmarks have collide = False (simple_spread.py:34)
-    __host__ __device__ static constexpr bool collides(int e) { return e < A_; }
-    __host__ __device__ static constexpr bool speaks(int) { return false; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int e) { return e < A_; }
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }
 
     // observation(), simple_spread.py:110-130
     template <typename T, class P>
@@ -163,9 +177,9 @@ struct TagCfg : CfgBase {
     static constexpr int OBS_ADV = 4 + 2 * L + 2 * (A - 1) + 2, OBS_GOOD = 4 + 2 * L + 2 * (A - 1);
     static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;
     static constexpr int NI = A, NF = 0, N_AUX = 0;
-    __host__ __device__ static constexpr bool collides(int) { return true; }   // simple_tag.py:19,30
-    __host__ __device__ static constexpr bool speaks(int) { return false; }
-    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int) { return true; }   // simple_tag.py:19,30
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }
+    __host__ __device__ __forceinline__ static constexpr bool adversary(int i) { return i < N_ADV; }
 
     // observation(), simple_tag.py:131-147
     template <typename T, class P>
@@ -238,10 +252,10 @@ struct WorldCommCfg : CfgBase {
     static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;                  // 192
     static constexpr int NI = A + 2, NF = 0, N_AUX = 0;
     // only agents and the obstacle collide (simple_world_comm.py:22,34,41,48)
-    __host__ __device__ static constexpr bool collides(int e) { return e <= A; }
-    __host__ __device__ static constexpr bool speaks(int i) { return i == 0; }
-    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
-    __host__ __device__ static constexpr bool leader(int i) { return i == 0; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int e) { return e <= A; }
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int i) { return i == 0; }
+    __host__ __device__ __forceinline__ static constexpr bool adversary(int i) { return i < N_ADV; }
+    __host__ __device__ __forceinline__ static constexpr bool leader(int i) { return i == 0; }
 
     template <typename T, class P>
     __device__ static __forceinline__ void forest_bits(const V2<T> (&pos)[E], const P& p, bool (&inf)[A][2]) {
@@ -261,9 +275,9 @@ struct WorldCommCfg : CfgBase {
     // through a tile of half the size: a 64 x 193 float32 tile is 49 KB of LDS, which leaves room for three
     // of these one-wave workgroups per CU, one short of its four SIMDs.
     static constexpr int OBS_CHUNKS = 2, CHUNK_MAX = OBS_TOTAL / 2, CHUNK_MIN = OBS_TOTAL / 2;
-    __host__ __device__ static constexpr int chunk_width(int) { return OBS_TOTAL / 2; }
-    __host__ __device__ static constexpr int chunk_offset(int c) { return c * (OBS_TOTAL / 2); }
-    __host__ __device__ static constexpr int obs_offset(int i) { return i < N_ADV ? i * OBS_ADV : N_ADV * OBS_ADV + (i - N_ADV) * OBS_GOOD; }
+    __host__ __device__ __forceinline__ static constexpr int chunk_width(int) { return OBS_TOTAL / 2; }
+    __host__ __device__ __forceinline__ static constexpr int chunk_offset(int c) { return c * (OBS_TOTAL / 2); }
+    __host__ __device__ __forceinline__ static constexpr int obs_offset(int i) { return i < N_ADV ? i * OBS_ADV : N_ADV * OBS_ADV + (i - N_ADV) * OBS_GOOD; }
 
     // in_forest bits of every agent (bit 2i+f), shared by the chunks of one step's observation
     template <typename T, class P>
@@ -425,8 +439,8 @@ struct SimpleCfg : CfgBase {
     static constexpr int DIM_C = 0, S = 0, N_ACT = 1;
     static constexpr int OBS_TOTAL = 2 + 2 * L;
     static constexpr int NI = 0, NF = 0, N_AUX = 0;    // no benchmark_data
-    __host__ __device__ static constexpr bool collides(int) { return false; }   // simple.py:12,18
-    __host__ __device__ static constexpr bool speaks(int) { return false; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int) { return false; }   // simple.py:12,18
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }
 
     // observation(), simple.py:45-50
     template <typename T, class P>
@@ -452,9 +466,9 @@ struct AdversaryCfg : CfgBase {
     static constexpr int OBS_ADV = 2 * L + 2 * (A - 1), OBS_GOOD = 2 + OBS_ADV;
     static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;
     static constexpr int NI = 1, NF = N_ADV + (A - N_ADV) * (L + 1), N_AUX = 1;
-    __host__ __device__ static constexpr bool collides(int) { return false; }   // simple_adversary.py:19,26
-    __host__ __device__ static constexpr bool speaks(int) { return false; }
-    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int) { return false; }   // simple_adversary.py:19,26
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }
+    __host__ __device__ __forceinline__ static constexpr bool adversary(int i) { return i < N_ADV; }
 
     // observation(), simple_adversary.py:119-138
     template <typename T, class P>
@@ -516,9 +530,9 @@ struct PushCfg : CfgBase {
     static constexpr int OBS_ADV = 2 + 2 * L + 2 * (A - 1), OBS_GOOD = 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1);
     static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;
     static constexpr int NI = 0, NF = 0, N_AUX = 1;     // no benchmark_data
-    __host__ __device__ static constexpr bool collides(int e) { return e < A; }   // simple_push.py:17,28
-    __host__ __device__ static constexpr bool speaks(int) { return false; }
-    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int e) { return e < A; }   // simple_push.py:17,28
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }
+    __host__ __device__ __forceinline__ static constexpr bool adversary(int i) { return i < N_ADV; }
 
     // observation(), simple_push.py:75-95.  Colours (reset_world :35-48): landmark l is 0.1 grey with
     // 0.8 added to channel l + 1; the good agent is 0.25 grey with 0.5 added to channel goal + 1.
@@ -580,9 +594,9 @@ struct SpeakerListenerCfg : CfgBase {
     static constexpr int OBS_TOTAL = 3 + (2 + 2 * L + DIM_C);
     static constexpr int NI = 1, NF = A, N_AUX = 1;          // info: goal index; the agents' own rewards
     static constexpr bool SHARED = true;                     // :11
-    __host__ __device__ static constexpr bool collides(int) { return false; }   // :16,26
-    __host__ __device__ static constexpr bool movable(int i) { return i == 1; } // :19
-    __host__ __device__ static constexpr bool speaks(int i) { return i == 0; }  // :21
+    __host__ __device__ __forceinline__ static constexpr bool collides(int) { return false; }   // :16,26
+    __host__ __device__ __forceinline__ static constexpr bool movable(int i) { return i == 1; } // :19
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int i) { return i == 0; }  // :21
 
     // observation() :69-91.  Landmark l is 0.15 grey with channel l at 0.65 (reset_world :45-47).
     template <typename T, class P>
@@ -618,8 +632,8 @@ struct ReferenceCfg : CfgBase {
     static constexpr int OBS_DIM = 2 + 2 * L + 3 + DIM_C, OBS_TOTAL = A * OBS_DIM;
     static constexpr int NI = 2, NF = A, N_AUX = 2;
     static constexpr bool SHARED = true;                     // :10
-    __host__ __device__ static constexpr bool collides(int) { return false; }   // :15,20
-    __host__ __device__ static constexpr bool speaks(int) { return true; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int) { return false; }   // :15,20
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return true; }
 
     // observation() :61-80.  Landmark l is 0.25 grey with channel l at 0.75 (reset_world :40-42).
     template <typename T, class P>
@@ -659,9 +673,9 @@ struct CryptoCfg : CfgBase {
     static constexpr int DIM_C = 4, S = 3, N_ACT = 3;
     static constexpr int OBS_TOTAL = DIM_C + 2 * DIM_C + 2 * DIM_C;
     static constexpr int NI = 2, NF = A * 2 * DIM_C, N_AUX = 2;
-    __host__ __device__ static constexpr bool collides(int) { return false; }   // :32,40
-    __host__ __device__ static constexpr bool movable(int) { return false; }    // :35
-    __host__ __device__ static constexpr bool speaks(int) { return true; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int) { return false; }   // :32,40
+    __host__ __device__ __forceinline__ static constexpr bool movable(int) { return false; }    // :35
+    __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return true; }
     static constexpr int SPEAKER = 2;                                           // :34
 
     // observation() :124-169: Eve hears Alice; Bob gets the key and hears Alice; Alice gets goal and key
@@ -732,16 +746,16 @@ struct PredatorPreyCfg : CfgBase {
     static constexpr int NI = A + 1, NF = 0, N_AUX = 3;           // info: collisions per agent, the flags
     static constexpr bool DYNAMIC = true, NEW_CORE = true;
     static constexpr int N_WALLS = 4;
-    __host__ __device__ static constexpr bool collides(int e) { return e <= A; }      // agents and the barrier (:34,47,56,65)
-    __host__ __device__ static constexpr bool adversary(int i) { return i < N_ADV; }
-    __host__ __device__ static constexpr bool leader(int i) { return i == 0 || i == GOOD_LEADER; }
-    __host__ __device__ static constexpr bool member(int i) { return i >= MEMBER0; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int e) { return e <= A; }      // agents and the barrier (:34,47,56,65)
+    __host__ __device__ __forceinline__ static constexpr bool adversary(int i) { return i < N_ADV; }
+    __host__ __device__ __forceinline__ static constexpr bool leader(int i) { return i == 0 || i == GOOD_LEADER; }
+    __host__ __device__ __forceinline__ static constexpr bool member(int i) { return i >= MEMBER0; }
     // adversaries, good agents, the barrier, foods and forests each share their properties (:39-41,49,58,67)
-    __host__ __device__ static constexpr int rep(int e) { return e < N_ADV ? 0 : (e < A ? N_ADV : (e == BARRIER ? BARRIER : (e < FOREST0 ? FOOD0 : FOREST0))); }
-    // one agent's 45 values at a time: a 64 x 315 tile (80 KB in float32) would leave one wave per CU
-    static constexpr int OBS_CHUNKS = A, CHUNK_MAX = OBS_DIM;
-    __host__ __device__ static constexpr int chunk_width(int) { return OBS_DIM; }
-    __host__ __device__ static constexpr int chunk_offset(int c) { return c * OBS_DIM; }
+    __host__ __device__ __forceinline__ static constexpr int rep(int e) { return e < N_ADV ? 0 : (e < A ? N_ADV : (e == BARRIER ? BARRIER : (e < FOREST0 ? FOOD0 : FOREST0))); }
+    // a 64 x 315 tile (80 KB in float32) would leave one wave per CU: 16 whole rows at a time
+    static constexpr int OBS_ROW_PASSES = 4;
+    __host__ __device__ __forceinline__ static constexpr int chunk_width(int) { return OBS_DIM; }
+    __host__ __device__ __forceinline__ static constexpr int chunk_offset(int c) { return c * OBS_DIM; }
 
     __device__ static __forceinline__ bool holds(int flags, int i) { return (flags >> (3 + i - MEMBER0)) & 1; }
 
@@ -759,55 +773,66 @@ struct PredatorPreyCfg : CfgBase {
         return (i1 && o1) || (i2 && o2) || (!i1 && !o1 && !i2 && !o2) || leader(i);
     }
 
-    // in_forest bits of every agent (bit 2i+f), shared by the chunks of one step's observation
+    // What one step's observations share: in_forest bits of every agent (bit 2i+f) and who sees whom (vis bit
+    // A*i+j: agent i sees agent j), worked out once per step, not once per agent and pass
+    struct ObsCtx { int forest; unsigned vis_lo, vis_hi; };
     template <typename T, class P>
-    __device__ static __forceinline__ int observe_prepare(const V2<T> (&pos)[E], const P& p) {
+    __device__ static __forceinline__ ObsCtx observe_prepare(const V2<T> (&pos)[E], const P& p) {
         bool inf[A][2];
         forest_bits<T>(pos, p, inf);
         int bits = 0;
 #pragma unroll
         for (int i = 0; i < A; ++i) bits |= (inf[i][0] ? 1 : 0) << (2 * i) | (inf[i][1] ? 1 : 0) << (2 * i + 1);
-        return bits;
+        unsigned long long vis = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int j = 0; j < A; ++j)
+                if (j != i && sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1])) vis |= 1ull << (A * i + j);
+        return ObsCtx{bits, (unsigned)vis, (unsigned)(vis >> 32)};
     }
 
     // observation() :300-349 of agents [I0, I1); offsets are cached_dist_vect[agent, other] = p_agent - p_other;
     // cast to float32
     template <typename T, int I0, int I1>
-    __device__ static __forceinline__ void observe_agents(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, int forest, T* row) {
-        bool inf[A][2];
-#pragma unroll
-        for (int i = 0; i < A; ++i) { inf[i][0] = (forest >> (2 * i)) & 1; inf[i][1] = (forest >> (2 * i + 1)) & 1; }
-        const int flags = aux[0];
+    __device__ static __forceinline__ void observe_agents(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, const ObsCtx& ctx, T* row) {
         int k = 0;
 #pragma unroll
         for (int i = I0; i < I1; ++i) {
-            // A chunk is computed between the barriers that bracket its tile; pinning the agent's own position
-            // here keeps the compiler from hoisting every chunk's arithmetic (315 live values) above the first.
+            // One agent's values are computed and stored at a time; pinning the agent's own position, the
+            // visibility bits and the flags here keeps the compiler from evaluating every agent's arithmetic and
+            // selects (315 live values) up front, or once for all passes over the rows.
             V2<T> me = pos[i];
+            int fbits = ctx.forest, flags = aux[0];
+            unsigned vlo = ctx.vis_lo, vhi = ctx.vis_hi;
             // (float32 only, see simple_world_comm's observe_cols)
             if constexpr (sizeof(T) == 4)
-                if (I1 - I0 == 1) asm volatile("" : "+v"(me.x), "+v"(me.y));
+                if (I1 - I0 == 1) asm volatile("" : "+v"(me.x), "+v"(me.y), "+v"(fbits), "+v"(flags), "+v"(vlo), "+v"(vhi));
+            const unsigned long long visbits = ((unsigned long long)vhi << 32) | vlo;
+            bool inf[A][2], seen[A];
+#pragma unroll
+            for (int j = 0; j < A; ++j) { inf[j][0] = (fbits >> (2 * j)) & 1; inf[j][1] = (fbits >> (2 * j + 1)) & 1; seen[j] = (visbits >> (A * i + j)) & 1; }
             row[k++] = round_f32(vel[i].x); row[k++] = round_f32(vel[i].y);
             row[k++] = round_f32(me.x); row[k++] = round_f32(me.y);
             if (member(i)) row[k++] = holds(flags, i) ? T(1) : T(-1);
 #pragma unroll
             for (int j = 0; j < A; ++j) {
                 if (j == i) continue;
-                const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
+                const bool vis = seen[j];
                 row[k++] = vis ? round_f32(me.x - pos[j].x) : T(0);
                 row[k++] = vis ? round_f32(me.y - pos[j].y) : T(0);
             }
 #pragma unroll
             for (int j = 0; j < A; ++j) {
                 if (j == i) continue;
-                const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
+                const bool vis = seen[j];
                 row[k++] = vis ? round_f32(vel[j].x) : T(0);
                 row[k++] = vis ? round_f32(vel[j].y) : T(0);
             }
 #pragma unroll
             for (int j = MEMBER0; j < A; ++j) {
                 if (j == i) continue;
-                const bool vis = sees(i, inf[i][0], inf[i][1], inf[j][0], inf[j][1]);
+                const bool vis = seen[j];
                 row[k++] = vis ? (holds(flags, j) ? T(1) : T(-1)) : T(0);
             }
 #pragma unroll
@@ -817,9 +842,20 @@ struct PredatorPreyCfg : CfgBase {
         }
     }
 
-    template <typename T, int C>
-    __device__ static __forceinline__ void observe_chunk(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, int forest, T* row) {
-        observe_agents<T, C, C + 1>(pos, vel, aux, forest, row);
+    // one pass of the row-pass scheme: agent by agent (each pinned, see observe_agents), stored by the pass's lanes
+    template <typename T, int I>
+    __device__ static __forceinline__ void pass_agents(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, const ObsCtx& ctx, T* row, bool mine) {
+        T vals[OBS_DIM];
+        observe_agents<T, I, I + 1>(pos, vel, aux, ctx, vals);
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < OBS_DIM; ++k) row[I * OBS_DIM + k] = vals[k];
+        }
+        if constexpr (I + 1 < A) pass_agents<T, I + 1>(pos, vel, aux, ctx, row, mine);
+    }
+    template <typename T, class P>
+    __device__ static __forceinline__ void observe_pass(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T*, const int* aux, const P& p, T* row, bool mine) {
+        pass_agents<T, 0>(pos, vel, aux, observe_prepare<T>(pos, p), row, mine);
     }
 
     template <typename T, class P>
@@ -996,11 +1032,11 @@ struct CollectorCfg : CfgBase {
     static constexpr int NI = 3 * A + 1, NF = 0, N_AUX = 3;       // info: (collected, deposited, collisions) per agent, the state word
     static constexpr bool DYNAMIC = true, NEW_CORE = true;
     static constexpr int OBS_CHUNKS = A, CHUNK_MAX = OBS_COL, CHUNK_MIN = OBS_DEP;
-    __host__ __device__ static constexpr int chunk_width(int c) { return c < NC ? OBS_COL : OBS_DEP; }
-    __host__ __device__ static constexpr int chunk_offset(int c) { return c < NC ? c * OBS_COL : NC * OBS_COL + (c - NC) * OBS_DEP; }
-    __host__ __device__ static constexpr bool collides(int e) { return e < A; }       // :40,57
+    __host__ __device__ __forceinline__ static constexpr int chunk_width(int c) { return c < NC ? OBS_COL : OBS_DEP; }
+    __host__ __device__ __forceinline__ static constexpr int chunk_offset(int c) { return c < NC ? c * OBS_COL : NC * OBS_COL + (c - NC) * OBS_DEP; }
+    __host__ __device__ __forceinline__ static constexpr bool collides(int e) { return e < A; }       // :40,57
     // collectors, deposits and treasures each share their properties (:44-47,59)
-    __host__ __device__ static constexpr int rep(int e) { return e < NC ? 0 : (e < A ? NC : A); }
+    __host__ __device__ __forceinline__ static constexpr int rep(int e) { return e < NC ? 0 : (e < A ? NC : A); }
 
     __device__ static __forceinline__ int held(int st, int a) { return ((st >> (2 * a)) & 3) - 1; }      // -1: nothing, else the type
     __device__ static __forceinline__ int ttype(int st, int l) { return (st >> (12 + l)) & 1; }

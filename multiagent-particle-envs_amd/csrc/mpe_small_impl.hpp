@@ -155,7 +155,10 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     constexpr int NC = Cfg::S * Cfg::DIM_C;      // comm state values: the speakers' utterances in agent order
     constexpr int OW = Cfg::OBS_CHUNKS > 1 ? Cfg::CHUNK_MAX : OT;        // columns held by the observation tile
     constexpr bool LIN = ((OW * (int)sizeof(T) / 4) % 16) != 0;
-    using ObsTile = Tile<T, OW, LIN, EPW>;
+    constexpr int RP = Cfg::OBS_ROW_PASSES;                              // > 0: the tile holds EPW / RP whole rows at a time
+    static_assert(RP == 0 || (Cfg::OBS_CHUNKS == 1 && !Cfg::OBS_LOOP && EPW % (RP > 0 ? RP : 1) == 0 && LIN), "row passes stream whole rows through a linear tile");
+    constexpr int TROWS = RP > 0 ? EPW / RP : EPW;
+    using ObsTile = Tile<T, OW, LIN, TROWS>;
     using RewTile = Tile<T, A, true, EPW>;
     using IiTile = Tile<int, NI, true, EPW>;
     using IfTile = Tile<T, NF, true, EPW>;
@@ -372,6 +375,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
                 }
             }
+            if (Cfg::PHASE_FENCES) __builtin_amdgcn_sched_barrier(0);
             // ---- wall contact for every movable entity, after its entity contacts (core.py:182-188) ----
             if (Cfg::N_WALLS > 0) {
 #pragma unroll
@@ -394,18 +398,21 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
                 }
             }
+            if (Cfg::PHASE_FENCES) __builtin_amdgcn_sched_barrier(0);
             // ---- World.integrate_state ----
 #pragma unroll
             for (int i = 0; i < A; ++i)
                 if (Cfg::movable(i)) integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[Cfg::rep(i)], p.max_speed[Cfg::rep(i)], p.one_minus_damping, p.dt);
         }
 
+        if (Cfg::PHASE_FENCES) __builtin_amdgcn_sched_barrier(0);
         // ---- scenario callbacks into the wave's LDS tiles ----
         const bool want_score = (MODE != MODE_OBSERVE) || (rew_g != nullptr);   // observe: rewards on request
         bool finished = false;
         if (EPW == 64 || lane < EPW) {
             if (want_score)
                 Cfg::template score<T>(pos, comm, aux, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
+            if (Cfg::PHASE_FENCES) __builtin_amdgcn_sched_barrier(0);
             if (Cfg::SHARED && MODE != MODE_OBSERVE) {
                 // collaborative world: step hands every agent np.sum(reward_n) (environment.py:103-105);
                 // numpy adds fewer than 8 values left to right
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
                 }
             }
-            if constexpr (Cfg::OBS_CHUNKS == 1) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
+            if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
         }
         const long long row0 = (long long)t * B + env0;
         if constexpr (Cfg::OBS_LOOP) {
@@ -486,14 +493,38 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 }
                 __syncthreads();
             }
+        } else if constexpr (RP > 0) {
+            // Whole rows, TROWS worlds at a time: every lane evaluates the observation in each pass, the lanes of
+            // the pass's worlds write their rows, and the tile -- a byte image of TROWS consecutive rows of the
+            // env-major array -- leaves as 16-byte vectors.  The arithmetic is repeated RP times, the stores are
+            // full 128-byte lines: a row that leaves in per-agent column pieces writes every line in several
+            // partial accesses, which alone takes as long as the whole launch (simple_predator_prey, 131 072
+            // worlds: pieces 1.36-1.46 ms, whole lines 0.73 ms with no arithmetic at all).
+#pragma unroll 1
+            for (int pass = 0; pass < RP; ++pass) {
+                const bool mine = (EPW == 64 || lane < EPW) && (lane / TROWS) == pass;
+                Cfg::template observe_pass<T>(pos, vel, comm, aux, p, tile_obs + (lane % TROWS) * OT, mine);
+                __syncthreads();
+                int nv = nvalid - pass * TROWS;
+                nv = nv < 0 ? 0 : (nv > TROWS ? TROWS : nv);
+                ObsTile::template flush<FULL>(tile_obs, obs_g + (row0 + pass * TROWS) * OT, lane, nv);
+                __syncthreads();
+            }
         } else if constexpr (Cfg::OBS_CHUNKS > 1)
-            ObsChunks<T, Cfg, 0, EPW, FULL>::run(pos, vel, comm, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_g + row0 * OT, lane,
+        {
+            // The flushes' index arithmetic depends on the lane alone, so the optimiser would compute it once
+            // before the step loop and keep every offset live throughout; an opaque copy of the lane makes it
+            // per-step work and frees those registers.
+            int lane_s = lane;
+            asm volatile("" : "+v"(lane_s));
+            ObsChunks<T, Cfg, 0, EPW, FULL>::run(pos, vel, comm, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_g + row0 * OT, lane_s,
                                                  tile_lane, EPW == 64 || lane < EPW, nvalid);
+        }
         // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
         // reset starts its episode untouched
         if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, (unsigned long long)b);
         __syncthreads();
-        if constexpr (Cfg::OBS_CHUNKS == 1) ObsTile::template flush<FULL>(tile_obs, obs_g + row0 * OT, lane, nvalid);
+        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0) ObsTile::template flush<FULL>(tile_obs, obs_g + row0 * OT, lane, nvalid);
         if (want_score) {
             RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane, nvalid);
             if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
