@@ -39,14 +39,6 @@ struct CfgBase {
     static constexpr int N_WALLS = 0;
     // > 1: the observation row is produced and streamed out in this many equal column chunks (one LDS
     // tile of a chunk's width instead of the whole row), through observe_prepare / observe_chunk<C>
-    // the instruction scheduler does not move code across the boundaries between the step's phases (contacts |
-    // walls | integration | reward | observation); for kernels whose straight-line step is thousands of
-    // instructions this bounds the values live at once
-#ifdef MPE_FENCES
-    static constexpr bool PHASE_FENCES = true;
-#else
-    static constexpr bool PHASE_FENCES = false;
-#endif
     static constexpr int OBS_CHUNKS = 1;
     static constexpr int CHUNK_MAX = 0, CHUNK_MIN = 0;     // widest / narrowest chunk; chunk c covers columns [chunk_offset(c), + chunk_width(c))
     // OBS_LOOP: the chunks are produced by ONE copy of the code, observe_agent(i, ...), run in a loop over

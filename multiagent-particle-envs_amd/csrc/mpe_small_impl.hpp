@@ -375,7 +375,6 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
                 }
             }
-            if (Cfg::PHASE_FENCES) __builtin_amdgcn_sched_barrier(0);
             // ---- wall contact for every movable entity, after its entity contacts (core.py:182-188) ----
             if (Cfg::N_WALLS > 0) {
 #pragma unroll
@@ -398,21 +397,18 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
                 }
             }
-            if (Cfg::PHASE_FENCES) __builtin_amdgcn_sched_barrier(0);
             // ---- World.integrate_state ----
 #pragma unroll
             for (int i = 0; i < A; ++i)
                 if (Cfg::movable(i)) integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[Cfg::rep(i)], p.max_speed[Cfg::rep(i)], p.one_minus_damping, p.dt);
         }
 
-        if (Cfg::PHASE_FENCES) __builtin_amdgcn_sched_barrier(0);
         // ---- scenario callbacks into the wave's LDS tiles ----
         const bool want_score = (MODE != MODE_OBSERVE) || (rew_g != nullptr);   // observe: rewards on request
         bool finished = false;
         if (EPW == 64 || lane < EPW) {
             if (want_score)
                 Cfg::template score<T>(pos, comm, aux, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
-            if (Cfg::PHASE_FENCES) __builtin_amdgcn_sched_barrier(0);
             if (Cfg::SHARED && MODE != MODE_OBSERVE) {
                 // collaborative world: step hands every agent np.sum(reward_n) (environment.py:103-105);
                 // numpy adds fewer than 8 values left to right
