@@ -477,15 +477,23 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 const int W = Cfg::chunk_width(i), S = ChunkTile<T, Cfg>::STRIDE;
                 if (active) Cfg::template observe_agent<T>(i, staged, aux, ctx, tile_obs + tile_lane * S);
                 __syncthreads();
-                T* gbase = obs_g + row0 * OT + Cfg::chunk_offset(i);
-                const int n = nvalid * W;
-                static_assert(!Cfg::OBS_LOOP || Cfg::CHUNK_MIN > 64, "the flush below assumes a 64-value stride crosses at most one row end");
+                // pairs of values: every chunk starts on an even column of an even-length row, so a pair is an
+                // 8-byte (float32) or 16-byte (float64) aligned access in the tile and in the array alike, and the
+                // flush takes half the instructions of a value-per-lane one
+                typedef T Pair __attribute__((ext_vector_type(2)));
+                static_assert(!Cfg::OBS_LOOP || (OT % 2 == 0 && S % 2 == 0 && Cfg::CHUNK_MIN % 2 == 0 && Cfg::CHUNK_MAX % 2 == 0), "pairs need even widths");
+                static_assert(!Cfg::OBS_LOOP || (Cfg::CHUNK_MIN / 2 > 32 && Cfg::CHUNK_MAX / 2 < 64), "a 64-pair stride crosses one or two row ends");
+                Pair* gbase = reinterpret_cast<Pair*>(obs_g + row0 * OT + Cfg::chunk_offset(i));
+                const Pair* tile2 = reinterpret_cast<const Pair*>(tile_obs);
+                const int W2 = W / 2, n = nvalid * W2;
                 int r = 0, j = lane;
+                if (j >= W2) { j -= W2; ++r; }
 #pragma unroll 4
                 for (int g = lane; g < n; g += 64) {
-                    gbase[(long long)r * OT + j] = tile_obs[r * S + j];
-                    j += 64;
-                    if (j >= W) { j -= W; ++r; }
+                    gbase[r * (OT / 2) + j] = tile2[r * (S / 2) + j];
+                    j += 64 - W2;
+                    ++r;
+                    if (j >= W2) { j -= W2; ++r; }
                 }
                 __syncthreads();
             }
