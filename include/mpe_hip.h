@@ -15,6 +15,8 @@
  *     pointer is refused with MPE_ERR_INVALID).  The library only holds the immutable world
  *     description and a small per-entity table in device memory.
  *   - Kernels are enqueued on the caller's stream and the call returns without synchronising.
+ *     A call makes the handle's device current for its launches and puts the caller's current
+ *     device back before it returns.
  *   - A handle is not thread-safe; distinct handles are independent.  There is no global state.
  *
  * Memory layout (T = float for MPE_F32, double for MPE_F64; B = n_envs; E = A + L entities,
