@@ -338,7 +338,8 @@ def main():
             "env_steps_per_s": value / A,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "small_kernel<%s, %s, %s>" % ("float" if s == 4 else "double", args.scenario, "rollout" if args.mode == "rollout" else "step"),
+                         "kernel": "%s<%s, %s, %s>" % ("consensus_kernel" if args.scenario == "consensus" else ("wave_kernel" if env.env_major else "small_kernel"),
+                                                       "float" if s == 4 else "double", args.scenario, "rollout" if args.mode == "rollout" else "step"),
                          "bytes_per_env_step": bytes_env_step, "bytes_per_launch": bytes_launch,
                          "launch_ms_hip_events": kern_ms, "launches": launches},
             "cpu_baseline": cpu,
