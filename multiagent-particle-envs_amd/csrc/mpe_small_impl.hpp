@@ -84,6 +84,9 @@ struct Tile {
 // block at gbase (row stride OT).  The tile's row stride is the widest chunk, made odd when that
 // width would put every lane's row on the same few LDS banks; chunks of such a tile whose width is
 // a whole number of 16-byte vectors leave as vectors, the others 4 bytes per lane.
+#ifndef MPE_ACTION_WORDS
+#define MPE_ACTION_WORDS 84      // action words a lane holds at once between a fetch and its packing
+#endif
 template <typename T, class Cfg>
 struct ChunkTile {
     static constexpr bool LINEAR = ((Cfg::CHUNK_MAX * (int)sizeof(T) / 4) % 16) != 0;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     constexpr int BITS = Cfg::BITS, ABITS = BITS * NA;
     constexpr unsigned AMASK = (1u << BITS) - 1u;
     constexpr int CH = (MODE == MODE_ROLLOUT) ? (128 / ABITS) : 1;
-    constexpr int NP_EPISODE = (25 + CH - 1) / CH, NP_BUDGET = 84 / (CH * NA) > 0 ? 84 / (CH * NA) : 1;
+    constexpr int NP_EPISODE = (25 + CH - 1) / CH, NP_BUDGET = MPE_ACTION_WORDS / (CH * NA) > 0 ? MPE_ACTION_WORDS / (CH * NA) : 1;
     constexpr int NP = (MODE == MODE_ROLLOUT) ? (NP_EPISODE < NP_BUDGET ? NP_EPISODE : NP_BUDGET) : 1;
     static_assert(ABITS <= 64, "one step's actions must fit 64 bits");
     unsigned __int128 fetched[NP] = {};
