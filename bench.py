@@ -17,6 +17,15 @@ Launch modes (--mode):
   graph    one mpe_step launch per step, the 25 launches of an episode replayed as one hipGraph
            (what an RL loop with a captured policy between steps would issue)
 
+--steps K / --warmup W: the timed region always holds whole 25-step episodes and at least
+TARGET_STEPS env steps, so that it is tens of milliseconds of GPU work and not one launch between two
+host synchronisations: the K-step block is repeated R times inside ONE timed region (timing_plan
+below); the line reports "steps" = R * K, the env steps that were actually timed, "steps_requested" = K
+and "repeats" = R.  Warm-up is W steps rounded up to whole episodes (at least two).
+
+--gpus N without WORLD_SIZE in the environment starts the N rank processes itself (fresh Python
+processes, before anything touches the GPU); under torch.distributed.run it joins the ranks it is given.
+
 Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   roofline      HBM roofline of the dominant kernel; achieved = algorithmic bytes per launch /
                 average launch duration from HIP event pairs inside the timed region, each
@@ -27,6 +36,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -37,6 +47,58 @@ sys.path.insert(0, os.path.join(ROOT, "multiagent-particle-envs_amd"))
 EPISODE = 25
 EVENT_GROUP = 4               # launches bracketed by one HIP event pair in rollout mode
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+TARGET_STEPS = 25000          # env steps a timed region holds at least (about 60 ms of the headline launch)
+STEP_MODE_STEPS = 1000        # env steps of the mpe_step / hipGraph comparison run
+STEP_MODE_WARMUP = 100
+
+
+def timing_plan(steps, warmup, episode=EPISODE, target=TARGET_STEPS):
+    """How a request for `steps` timed and `warmup` untimed env steps is run.
+
+    The block of `steps` env steps is repeated `repeats` times in one timed region.  While the
+    request is shorter than `target`, repeats is the smallest count that reaches `target` AND makes
+    the region a whole number of episodes (every launch is then the full reset + `episode` steps
+    launch); a request of `target` steps or more runs once, its last launch a partial episode when
+    `steps` is not a multiple of `episode`.  Warm-up is rounded up to whole episodes, two at least.
+    """
+    if steps < 1:
+        raise ValueError("--steps must be >= 1")
+    if warmup < 0:
+        raise ValueError("--warmup must be >= 0")
+    if steps >= target:
+        repeats = 1
+    else:
+        unit = episode // math.gcd(steps, episode)      # repeats must be a multiple of this
+        repeats = -(-target // steps)
+        repeats = -(-repeats // unit) * unit
+    timed = repeats * steps
+    return {"steps_requested": steps, "repeats": repeats, "timed_steps": timed,
+            "full_launches": timed // episode, "tail_steps": timed % episode,
+            "warmup_requested": warmup, "warmup_steps": max(2, -(-warmup // episode)) * episode}
+
+
+def source_hash():
+    """sha256 over the kernel sources and the C header: identifies the build a stored counter figure belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "multiagent-particle-envs_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    for fn in files + [os.path.join(ROOT, "include", "mpe_hip.h")]:
+        h.update(os.path.basename(fn).encode() + b"\0")
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def stored_traffic(key):
+    """HBM bytes per launch from the rocprofv3 counter passes (tools/collect_profiles.py), or None when
+    the stored figure was not measured on this build of the kernels."""
+    try:
+        entry = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
+    except (OSError, KeyError, ValueError):
+        return None
+    if entry.get("source_hash") != source_hash():
+        return None
+    return entry.get("hbm_bytes_per_launch")
 
 # Algorithmic bytes per env-step, float32 (s = 4), int32 actions, 1-byte done.
 #   step launch:    reads  agent pos+vel 4A*s, landmark pos 2L*s, actions 4*n_act
@@ -111,9 +173,7 @@ def cpu_baseline_processes(n_procs, seconds=6.0):
             "sample": "%d processes x one simple_spread env, %.1f s each" % (n_procs, seconds)}
 
 
-def main():
-    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
-        return _cpu_worker(float(sys.argv[2]))
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2500)
@@ -126,9 +186,14 @@ def main():
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step", "graph"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-device", action="store_true",
-                    help="rehearsal only: every rank uses GPU 0 (a one-GPU box cannot host the real N > 1 run)")
+                    help="rehearsal only: every rank uses GPU 0 and the ranks talk over gloo (a one-GPU box cannot host the real N > 1 run)")
+    ap.add_argument("--dry", action="store_true",
+                    help="rehearsal of the multi-process path without a GPU: ranks rendezvous (use --backend gloo), shard the env "
+                         "index, all-reduce synthetic statistics and rank 0 prints the plan; nothing is simulated or timed")
     ap.add_argument("--episodes-per-launch", type=int, default=1,
                     help="rollout mode: consecutive episodes (each with its own on-device reset) per mpe_episodes launch")
+    ap.add_argument("--target-steps", type=int, default=TARGET_STEPS,
+                    help="the timed region holds at least this many env steps (the --steps block is repeated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=min(16, os.cpu_count() or 1),
                     help="processes of the N-process CPU figure (0 = skip); a one-GPU box's CPU share is 16")
@@ -136,17 +201,90 @@ def main():
     ap.add_argument("--event-every", type=int, default=4,
                     help="time every k-th group of 4 episode launches with one HIP event pair (a pair costs ~7 us on the "
                          "stream, so pairs around every launch would throttle submission and inflate the average)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(n, argv):
+    """Starts the n rank processes of a --gpus n run and waits for them; returns the exit code.
+
+    Called before torch is imported: this process never touches the GPU and replaces nothing, it
+    only starts fresh interpreters with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what
+    torch.distributed.run would set) and lets them inherit stdout, on which rank 0 prints the line.
+    """
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    code = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0 and code == 0:
+                code = rc
+                for q in pending:           # a rank failed: the others would wait in a barrier for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return code
+
+
+def dry_run(args, world, rank):
+    """The multi-process path without a GPU: rendezvous, shards, the statistics all-reduce, one line."""
     import torch
     import torch.distributed as dist
+    from mpe_hip.dist import EpisodeStats, shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.backend == "nccl" else args.backend, rank=rank, world_size=world)
+    first_env, last_env = shard_range(world * args.envs, rank, world)
+    stats = EpisodeStats("cpu")
+    # rewards derived from the global env index so that the global sum is known: -sum(range(world * envs))
+    stats.add_episode(-torch.arange(first_env, last_env, dtype=torch.float64).view(1, -1, 1).expand(1, -1, args.agents))
+    total = stats.reduce()
+    shards = [None] * world
+    if world > 1:
+        dist.all_gather_object(shards, (first_env, last_env))
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        shards = [(first_env, last_env)]
+    if rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": world, "plan": timing_plan(args.steps, args.warmup, target=args.target_steps),
+                          "shards": shards, "stats": total}))
+
+
+def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(float(sys.argv[2]))
+    args = parse_args()
+    plan = timing_plan(args.steps, args.warmup, target=args.target_steps)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry:
+        return dry_run(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
+
     dev_index = 0 if args.share_device else local_rank
+    if args.share_device and args.backend == "nccl":
+        args.backend = "gloo"       # RCCL refuses two ranks on one device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -172,8 +310,9 @@ def main():
     for col, n in enumerate(env.action_dims):        # comm words are uniform over dim_c
         if n != 5:
             actions[:, :, col] = torch.randint(0, n, (K * EPISODE, B), generator=gen, device=dev, dtype=torch.int32)
-    out = None
-    pairs = []                                  # (start, end, steps) events around dominant-kernel launches
+    outs = {}                                   # rollout output buffers by step count (full and partial launches)
+    last = {"out": None}
+    pairs = []                                  # (start, end, launches or steps) events around dominant-kernel launches
     graphs = {}
 
     def episode_graph():
@@ -193,8 +332,7 @@ def main():
 
     def run(n_steps, mode, record):
         """n_steps env steps in episodes of EPISODE; returns the number of dominant-kernel launches."""
-        nonlocal out
-        done_steps, launches, ep = 0, 0, 0
+        done_steps, launches = 0, 0
         open_pair = None
         while done_steps < n_steps:
             n = min(EPISODE, n_steps - done_steps)
@@ -205,21 +343,22 @@ def main():
             if mode != "rollout":
                 env.reset(seed=1234 + first_env)
             if mode == "rollout":
-                # one event pair brackets EVENT_GROUP consecutive launches (an event pair costs
+                # one event pair brackets EVENT_GROUP consecutive full launches (an event pair costs
                 # about 7 us on the stream, a tenth of one launch), every event_every-th group
                 grp = launches // EVENT_GROUP
                 rec = record and n == K * EPISODE and (grp % args.event_every == 0)
                 if rec and launches % EVENT_GROUP == 0:
-                    e0 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    open_pair = e0
+                    open_pair = torch.cuda.Event(enable_timing=True)
+                    open_pair.record()
+                elif not rec:
+                    open_pair = None
                 # mpe_episode: on-device reset of every env + n steps in one launch
-                out = env.rollout(actions[:n], out if (out is not None and out["obs"].shape[0] == n) else None,
-                                  reset_seed=1234 + first_env, episodes=k_ep)
+                outs[n] = env.rollout(actions[:n], outs.get(n), reset_seed=1234 + first_env, episodes=k_ep)
+                last["out"] = outs[n]
                 if rec and launches % EVENT_GROUP == EVENT_GROUP - 1 and open_pair is not None:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
-                    pairs.append((open_pair, e1, n * EVENT_GROUP))
+                    pairs.append((open_pair, e1, EVENT_GROUP))
                     open_pair = None
                 launches += 1
             elif mode == "graph" and n == EPISODE:
@@ -234,16 +373,16 @@ def main():
                 launches += n
             else:
                 for t in range(n):
-                    if record:
+                    rec = record and (launches % 8 == 0)
+                    if rec:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                     env.step(actions[t])
-                    if record:
+                    if rec:
                         e1.record()
                         pairs.append((e0, e1, 1))
                     launches += 1
             done_steps += n
-            ep += 1
         return launches
 
     def barrier():
@@ -259,24 +398,28 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, launches
 
-    run(args.warmup, args.mode, False)
-    elapsed, launches = timed(args.steps, args.mode, True)
-    steps_per_launch = K * EPISODE if args.mode == "rollout" else 1
+    def event_average():
+        """Mean duration in ms of what one recorded unit covers (a launch, or a step of a graph replay)."""
+        units = sum(n for _, _, n in pairs)
+        if units == 0:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b, _ in pairs) / units
+        return ms if ms > 0.0 else None
+
+    run(plan["warmup_steps"], args.mode, False)
+    elapsed, launches = timed(plan["timed_steps"], args.mode, True)
+    timed_steps = plan["timed_steps"]
     # average duration of one dominant-kernel launch and the env steps it covers (a graph replay
     # holds EPISODE single-step launches, so its time is divided by the steps it ran)
-    tot_ms = sum(a.elapsed_time(b) for a, b, _ in pairs)
-    if args.mode == "rollout":
-        kern_ms, avg_steps = tot_ms / max(1, len(pairs) * EVENT_GROUP), float(K * EPISODE)
-    else:
-        kern_ms, avg_steps = tot_ms / max(1, sum(n for _, _, n in pairs)), 1.0
-
-    if not pairs or kern_ms <= 0.0:          # too few launches for an event group: fall back to the wall clock
-        kern_ms = elapsed * 1e3 / max(1, launches)
+    avg_steps = float(K * EPISODE) if args.mode == "rollout" else 1.0
+    kern_ms, kern_src = event_average(), "hip_events"
+    if kern_ms is None:         # no complete event group (a request of a few launches only): the wall clock
+        kern_ms, kern_src = elapsed * 1e3 / max(1.0, timed_steps / avg_steps), "wall_clock"
     s = 4 if args.dtype == "f32" else 8
     lo = env.layout
     # an episode's state write-back is once per launch; every episode of a launch is counted as if it wrote it
@@ -289,44 +432,33 @@ def main():
     if args.mode == "rollout" and not args.no_step_mode:
         pairs_saved = list(pairs)
         pairs.clear()
-        n2 = min(args.steps, 1000)
-        n2 -= n2 % EPISODE
-        run(min(args.warmup, 100), "graph", False)
-        dt2, _ = timed(n2, "graph", True)
-        k2 = sum(a.elapsed_time(b) for a, b, _ in pairs) / max(1, sum(n for _, _, n in pairs))
+        run(STEP_MODE_WARMUP, "graph", False)
+        dt2, _ = timed(STEP_MODE_STEPS, "graph", True)
+        k2 = event_average() or dt2 * 1e3 / STEP_MODE_STEPS
         b2 = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, 1) * B
-        step_mode = {"value": world * B * A * n2 / dt2, "unit": "agent-steps/s", "steps": n2, "ms_per_step": dt2 * 1e3 / n2,
+        step_mode = {"value": world * B * A * STEP_MODE_STEPS / dt2, "unit": "agent-steps/s", "steps": STEP_MODE_STEPS,
+                     "ms_per_step": dt2 * 1e3 / STEP_MODE_STEPS,
                      "launch": "mpe_step, 1 step/launch, %d launches per hipGraph replay" % EPISODE, "launch_ms_hip_events": k2,
                      "roofline_frac": b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_env_step": b2 / B}
         pairs[:] = pairs_saved
 
     # optional statistics all-reduce (RCCL), outside every timed region: return of agent 0 over the last episode
     stats = EpisodeStats(dev)
-    stats.add_episode(out["rew"][-EPISODE:] if out is not None else env.rew)
+    stats.add_episode(last["out"]["rew"][-EPISODE:] if last["out"] is not None else env.rew)
     tot = stats.reduce()
     mean_rew0 = tot["return_agent0"] / max(1.0, tot["episodes"])
-
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = "%s_%s_B%d_%s" % (args.scenario, args.dtype, B, args.mode)
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
 
     if rank == 0:
         cpu = None if args.no_cpu_baseline else cpu_baseline()
         if cpu is not None and args.cpu_procs > 1:
             cpu["n_process"] = cpu_baseline_processes(args.cpu_procs)
-        value = world * B * A * args.steps / elapsed
+        value = world * B * A * timed_steps / elapsed
         line = {
             "metric": "agent-steps/sec (whole node) batched simple_spread N=3" if args.scenario == "simple_spread" and A == 3
                       else "agent-steps/sec (whole node) batched %s" % args.scenario,
-            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": timed_steps, "warmup": plan["warmup_steps"],
+            "steps_requested": args.steps, "warmup_requested": args.warmup, "repeats": plan["repeats"],
+            "elapsed_s": elapsed, "ms_per_step": elapsed * 1e3 / timed_steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s A=%d L=%d, %d envs/GPU, %d-step episodes, uniform random int actions, on-device reset each episode"
                                    % (args.scenario, A, env.n_landmarks, B, EPISODE),
@@ -334,19 +466,23 @@ def main():
                        "launch": {"rollout": ("mpe_episode (on-device reset + %d steps) per launch" % EPISODE) if K == 1 else
                                              ("mpe_episodes: %d x (on-device reset + %d steps) per launch" % (K, EPISODE)), "step": "mpe_step, 1 step/launch, eager",
                                   "graph": "mpe_step, 1 step/launch, %d launches per hipGraph replay" % EPISODE}[args.mode],
+                       "timed_region": "the %d-step request repeated %d times between one pair of barrier + synchronize" % (args.steps, plan["repeats"]),
                        "parallelism": "env-index shards, no data-path collective"},
             "env_steps_per_s": value / A,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # counters are not collected in a timing run: the figure is the stored rocprofv3 measurement
+                         # of this very build of the kernels, null otherwise
+                         "traffic": stored_traffic("%s_%s_B%d_%s" % (args.scenario, args.dtype, B, args.mode)),
                          "kernel": "%s<%s, %s, %s>" % ("consensus_kernel" if args.scenario == "consensus" else ("wave_kernel" if env.env_major else "small_kernel"),
                                                        "float" if s == 4 else "double", args.scenario, "rollout" if args.mode == "rollout" else "step"),
                          "bytes_per_env_step": bytes_env_step, "bytes_per_launch": bytes_launch,
-                         "launch_ms_hip_events": kern_ms, "launches": launches},
+                         "launch_ms": kern_ms, "launch_ms_source": kern_src, "event_pairs": len(pairs), "launches": launches},
             "cpu_baseline": cpu,
             "step_mode": step_mode,
             "mean_episode_return_agent0": mean_rew0,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -41,5 +41,7 @@ class EpisodeStats:
         """Global sums as a dict (identical on every rank)."""
         total = self.sums.clone()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if dist.get_backend(group) == "gloo":
+                total = total.cpu()         # gloo reduces host memory
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
         return dict(zip(self.FIELDS, total.tolist()))
