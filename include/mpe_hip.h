@@ -11,9 +11,12 @@
  *     thrown across the boundary.  mpe_last_error() returns a description of the last failure
  *     on a handle (or of the last failed mpe_create when called with NULL).
  *   - The caller allocates and owns every buffer.  All data pointers are DEVICE pointers on the
- *     handle's device and 16-byte aligned (rows leave the kernels as 16-byte vectors; a misaligned
- *     pointer is refused with MPE_ERR_INVALID).  The library only holds the immutable world
- *     description and a small per-entity table in device memory.
+ *     handle's device.  Output buffers (obs, rew, done, info_i, info_f) are 16-byte aligned: their
+ *     rows leave the kernels as 16-byte vectors.  Inputs and state (actions, pos, vel, comm, aux)
+ *     need the alignment of their element type only, so a step may read a slice actions[t] of a
+ *     pre-generated [T][B][n_act] array whatever B is.  A misaligned pointer is refused with
+ *     MPE_ERR_INVALID.  The library only holds the immutable world description and a small
+ *     per-entity table in device memory.
  *   - Kernels are enqueued on the caller's stream and the call returns without synchronising.
  *     A call makes the handle's device current for its launches and puts the caller's current
  *     device back before it returns.
@@ -126,8 +129,10 @@ typedef struct MpeSpec {
     const uint8_t* silent;    /* [A] Agent.silent */
     const uint8_t* adversary; /* [A] agent.adversary (simple_tag.py:21); zeros otherwise */
     const uint8_t* leader;    /* [A] agent.leader (simple_world_comm.py:23); zeros otherwise */
-    /* World.walls (core.py:26-42), simulated by mpe_world_step only (MPE_SCN_NONE); n_walls == 0
-     * and NULL pointers for the built-in scenarios, none of which has walls. */
+    /* World.walls (core.py:26-42; new_core.py walls of the arena scenarios).  mpe_world_step
+     * (MPE_SCN_NONE) simulates any 0..MPE_MAX_WALLS walls; simple_predator_prey and consensus need
+     * exactly their 4 arena walls (mpe_create checks); every other built-in scenario has none
+     * (n_walls == 0, NULL pointers). */
     int32_t n_walls;
     int32_t collaborative; /* World.collaborative (environment.py:38): must match the scenario (1 for
                               simple_speaker_listener and simple_reference, 0 for the others) */

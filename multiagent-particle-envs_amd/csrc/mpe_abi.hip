@@ -226,41 +226,32 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
     lo->n_hist_rows = (s.scenario == MPE_SCN_CONSENSUS) ? 10 * A * 4 : 0;
 }
 
-extern "C" {
-
-int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHandle** out) {
-    if (!out) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: out is NULL");
-    *out = nullptr;
-    if (!spec) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: spec is NULL");
-    if (n_envs <= 0) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: n_envs must be positive (got %lld)", (long long)n_envs);
-    if (dtype != MPE_F32 && dtype != MPE_F64) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: dtype must be MPE_F32 or MPE_F64");
+// Validates an MpeSpec and copies it into `s`; errors are recorded for mpe_last_error(NULL).
+static int read_spec(const MpeSpec* spec, int64_t n_envs, int dtype, int device, HostSpec& s, const char* who) {
+    if (!spec) return fail(nullptr, MPE_ERR_INVALID, "%s: spec is NULL", who);
+    if (n_envs <= 0) return fail(nullptr, MPE_ERR_INVALID, "%s: n_envs must be positive (got %lld)", who, (long long)n_envs);
+    if (dtype != MPE_F32 && dtype != MPE_F64) return fail(nullptr, MPE_ERR_INVALID, "%s: dtype must be MPE_F32 or MPE_F64", who);
     const int A = spec->n_agents, L = spec->n_landmarks;
     if (A < 1 || A > MPE_MAX_AGENTS || L < 0 || L > MPE_MAX_LANDMARKS)
-        return fail(nullptr, MPE_ERR_INVALID, "mpe_create: need 1..%d agents and 0..%d landmarks (got %d, %d)", MPE_MAX_AGENTS, MPE_MAX_LANDMARKS, A, L);
+        return fail(nullptr, MPE_ERR_INVALID, "%s: need 1..%d agents and 0..%d landmarks (got %d, %d)", who, MPE_MAX_AGENTS, MPE_MAX_LANDMARKS, A, L);
     if (!spec->size || !spec->mass || !spec->movable || !spec->collide || !spec->sensitivity || !spec->max_speed || !spec->silent)
-        return fail(nullptr, MPE_ERR_INVALID, "mpe_create: a required per-entity array is NULL");
-    if (spec->dim_c < 0 || spec->dim_c > 16) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: dim_c out of range");
-    if (!(spec->contact_margin > 0) || !(spec->dt > 0)) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: dt and contact_margin must be positive");
+        return fail(nullptr, MPE_ERR_INVALID, "%s: a required per-entity array is NULL", who);
+    if (spec->dim_c < 0 || spec->dim_c > 16) return fail(nullptr, MPE_ERR_INVALID, "%s: dim_c out of range", who);
+    if (!(spec->contact_margin > 0) || !(spec->dt > 0)) return fail(nullptr, MPE_ERR_INVALID, "%s: dt and contact_margin must be positive", who);
 
-    MpeHandle* h = new (std::nothrow) MpeHandle();
-    if (!h) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: out of host memory");
-    memset(h, 0, sizeof(*h));
-    HostSpec& s = h->spec;
     s.scenario = spec->scenario; s.A = A; s.L = L; s.dim_c = spec->dim_c; s.collaborative = spec->collaborative ? 1 : 0;
     s.physics = spec->physics;
-    if (s.physics != MPE_PHYSICS_CORE && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: unknown physics %d", s.physics); }
+    if (s.physics != MPE_PHYSICS_CORE && s.physics != MPE_PHYSICS_NEW_CORE) return fail(nullptr, MPE_ERR_INVALID, "%s: unknown physics %d", who, s.physics);
     const bool new_core_scn = spec->scenario == MPE_SCN_PREDATOR_PREY || spec->scenario == MPE_SCN_CONSENSUS || spec->scenario == MPE_SCN_COLLECTOR;
-    if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE && !new_core_scn) {
-        delete h;
-        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: new_core physics is simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey, consensus and collector only");
-    }
-    if (new_core_scn && s.physics != MPE_PHYSICS_NEW_CORE) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: this scenario runs on the new_core physics"); }
-    if (s.physics == MPE_PHYSICS_NEW_CORE && !spec->accel) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: new_core physics needs the accel array"); }
+    if (s.physics == MPE_PHYSICS_NEW_CORE && spec->scenario != MPE_SCN_NONE && !new_core_scn)
+        return fail(nullptr, MPE_ERR_UNSUPPORTED, "%s: new_core physics is simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey, consensus and collector only", who);
+    if (new_core_scn && s.physics != MPE_PHYSICS_NEW_CORE) return fail(nullptr, MPE_ERR_INVALID, "%s: this scenario runs on the new_core physics", who);
+    if (s.physics == MPE_PHYSICS_NEW_CORE && !spec->accel) return fail(nullptr, MPE_ERR_INVALID, "%s: new_core physics needs the accel array", who);
     s.dt = spec->dt; s.damping = spec->damping; s.contact_force = spec->contact_force; s.contact_margin = spec->contact_margin;
     for (int e = 0; e < A + L; ++e) {
         s.size[e] = spec->size[e]; s.mass[e] = spec->mass[e];
         s.movable[e] = spec->movable[e] ? 1 : 0; s.collide[e] = spec->collide[e] ? 1 : 0;
-        if (!(s.mass[e] > 0)) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: entity %d has non-positive mass", e); }
+        if (!(s.mass[e] > 0)) return fail(nullptr, MPE_ERR_INVALID, "%s: entity %d has non-positive mass", who, e);
     }
     for (int i = 0; i < A; ++i) {
         s.sens[i] = spec->sensitivity[i]; s.max_speed[i] = spec->max_speed[i];
@@ -268,54 +259,71 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
         s.adversary[i] = (spec->adversary && spec->adversary[i]) ? 1 : 0;
         s.leader[i] = (spec->leader && spec->leader[i]) ? 1 : 0;
         s.ghost[i] = (spec->ghost && spec->ghost[i]) ? 1 : 0;
-        if (isnan(s.max_speed[i])) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: max_speed[%d] is NaN (use +inf for no limit)", i); }
+        if (isnan(s.max_speed[i])) return fail(nullptr, MPE_ERR_INVALID, "%s: max_speed[%d] is NaN (use +inf for no limit)", who, i);
         s.force_scale[i] = 1.0;
         if (s.physics == MPE_PHYSICS_NEW_CORE) s.force_scale[i] = isnan(spec->accel[i]) ? s.mass[i] : s.mass[i] * spec->accel[i];
     }
     s.n_walls = spec->n_walls;
-    if (s.n_walls < 0 || s.n_walls > MPE_MAX_WALLS) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: 0..%d walls (got %d)", MPE_MAX_WALLS, spec->n_walls); }
+    if (s.n_walls < 0 || s.n_walls > MPE_MAX_WALLS) return fail(nullptr, MPE_ERR_INVALID, "%s: 0..%d walls (got %d)", who, MPE_MAX_WALLS, spec->n_walls);
     if (s.n_walls > 0) {
-        if (spec->scenario != MPE_SCN_NONE && !new_core_scn) { delete h; return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: walls are simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey, consensus and collector only"); }
-        if (!spec->wall_vertical || !spec->wall_axis_pos || !spec->wall_end0 || !spec->wall_end1 || !spec->wall_width || !spec->wall_hard) {
-            delete h;
-            return fail(nullptr, MPE_ERR_INVALID, "mpe_create: a wall array is NULL");
-        }
+        if (spec->scenario != MPE_SCN_NONE && !new_core_scn)
+            return fail(nullptr, MPE_ERR_UNSUPPORTED, "%s: walls are simulated by mpe_world_step (MPE_SCN_NONE), simple_predator_prey, consensus and collector only", who);
+        if (!spec->wall_vertical || !spec->wall_axis_pos || !spec->wall_end0 || !spec->wall_end1 || !spec->wall_width || !spec->wall_hard)
+            return fail(nullptr, MPE_ERR_INVALID, "%s: a wall array is NULL", who);
         for (int w = 0; w < s.n_walls; ++w) {
             s.wall_vertical[w] = spec->wall_vertical[w] ? 1 : 0; s.wall_hard[w] = spec->wall_hard[w] ? 1 : 0;
             s.wall_axis_pos[w] = spec->wall_axis_pos[w]; s.wall_end0[w] = spec->wall_end0[w];
             s.wall_end1[w] = spec->wall_end1[w]; s.wall_width[w] = spec->wall_width[w];
         }
     }
-    if (const char* why = check_structure(s)) {
-        delete h;
-        return fail(nullptr, MPE_ERR_INVALID, "mpe_create: spec does not match scenario %d: %s", spec->scenario, why);
-    }
+    if (const char* why = check_structure(s)) return fail(nullptr, MPE_ERR_INVALID, "%s: spec does not match scenario %d: %s", who, spec->scenario, why);
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
-    if (e != hipSuccess) { delete h; return hip_fail(nullptr, e, "hipGetDeviceCount"); }
-    if (device < 0 || device >= n_dev) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: device %d out of range (%d visible)", device, n_dev); }
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceCount");
+    if (device < 0 || device >= n_dev) return fail(nullptr, MPE_ERR_INVALID, "%s: device %d out of range (%d visible)", who, device, n_dev);
+    return MPE_OK;
+}
+
+// The per-entity table the wave-per-world kernels read from device memory; unused entries are zero.
+static void fill_table(const HostSpec& s, DevTable& t) {
+    memset(&t, 0, sizeof(t));
+    const int A = s.A, L = s.L;
+    for (int k = 0; k < A + L; ++k) { t.size[k] = s.size[k]; t.mass[k] = s.mass[k]; t.collide[k] = s.collide[k]; t.movable[k] = s.movable[k]; }
+    for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; t.ghost[i] = s.ghost[i]; t.force_scale[i] = s.force_scale[i]; }
+    t.n_walls = s.n_walls;
+    t.new_core = s.physics == MPE_PHYSICS_NEW_CORE ? 1 : 0;
+    for (int w = 0; w < s.n_walls; ++w) {
+        t.wall_vertical[w] = s.wall_vertical[w]; t.wall_hard[w] = s.wall_hard[w]; t.wall_axis_pos[w] = s.wall_axis_pos[w];
+        t.wall_end0[w] = s.wall_end0[w]; t.wall_end1[w] = s.wall_end1[w]; t.wall_width[w] = s.wall_width[w];
+    }
+}
+
+extern "C" {
+
+int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHandle** out) {
+    if (!out) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: out is NULL");
+    *out = nullptr;
+    MpeHandle* h = new (std::nothrow) MpeHandle();
+    if (!h) return fail(nullptr, MPE_ERR_INVALID, "mpe_create: out of host memory");
+    memset(h, 0, sizeof(*h));
+    HostSpec& s = h->spec;
+    int rc = read_spec(spec, n_envs, dtype, device, s, "mpe_create");
+    if (rc != MPE_OK) { delete h; return rc; }
     h->dtype = dtype;
     h->device = device;
     fill_layout(s, n_envs, &h->layout);
     h->use_wave = !small_supported(s) && s.scenario != MPE_SCN_CONSENSUS;
     if (h->use_wave && !wave_supported(s)) {
         delete h;
-        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: no kernel for scenario %d with %d agents / %d landmarks", s.scenario, A, L);
+        return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: no kernel for scenario %d with %d agents / %d landmarks", s.scenario, s.A, s.L);
     }
     h->layout.state_env_major = h->use_wave ? 1 : 0;
     if (h->use_wave) {
         if (n_envs > 0x7fffffffLL) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: at most 2^31-1 envs for this scenario size"); }
         DevTable t;
-        memset(&t, 0, sizeof(t));
-        for (int k = 0; k < A + L; ++k) { t.size[k] = s.size[k]; t.mass[k] = s.mass[k]; t.collide[k] = s.collide[k]; t.movable[k] = s.movable[k]; }
-        for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; t.ghost[i] = s.ghost[i]; t.force_scale[i] = s.force_scale[i]; }
-        t.n_walls = s.n_walls;
-        t.new_core = s.physics == MPE_PHYSICS_NEW_CORE ? 1 : 0;
-        for (int w = 0; w < s.n_walls; ++w) {
-            t.wall_vertical[w] = s.wall_vertical[w]; t.wall_hard[w] = s.wall_hard[w]; t.wall_axis_pos[w] = s.wall_axis_pos[w];
-            t.wall_end0[w] = s.wall_end0[w]; t.wall_end1[w] = s.wall_end1[w]; t.wall_width[w] = s.wall_width[w];
-        }
+        fill_table(s, t);
         DeviceScope scope(device);
+        hipError_t e;
         if ((e = scope.status) != hipSuccess || (e = hipMalloc((void**)&h->table, sizeof(DevTable))) != hipSuccess ||
             (e = hipMemcpy(h->table, &t, sizeof(DevTable), hipMemcpyHostToDevice)) != hipSuccess) {
             if (h->table) (void)hipFree(h->table);
@@ -357,10 +365,15 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
     if (a.info_f && !a.info_i) return fail(h, MPE_ERR_INVALID, "%s: info_f requires info_i", who);
     if (a.info_i && h->layout.n_info_i == 0) return fail(h, MPE_ERR_INVALID, "%s: this scenario has no benchmark_data; info_i must be NULL", who);
     if (h->layout.n_aux > 0 && !a.aux) return fail(h, MPE_ERR_INVALID, "%s: aux must not be NULL for a scenario with a goal landmark", who);
-    // rows leave the kernels as 16-byte vectors
-    const void* bufs[] = {a.pos, a.vel, a.comm, a.obs, a.rew, a.done, a.info_i, a.info_f, a.actions, a.aux};
-    for (const void* ptr : bufs)
-        if (((uintptr_t)ptr & 15u) != 0) return fail(h, MPE_ERR_INVALID, "%s: every buffer must be 16-byte aligned (got %p)", who, ptr);
+    // output rows leave the kernels as 16-byte vectors; actions and state are read and written one element at a time
+    const void* outs[] = {a.obs, a.rew, a.done, a.info_i, a.info_f};
+    for (const void* ptr : outs)
+        if (((uintptr_t)ptr & 15u) != 0) return fail(h, MPE_ERR_INVALID, "%s: every output buffer must be 16-byte aligned (got %p)", who, ptr);
+    const uintptr_t elem = h->dtype == MPE_F64 ? 8u : 4u;
+    const void* state[] = {a.pos, a.vel, a.comm};
+    for (const void* ptr : state)
+        if (((uintptr_t)ptr & (elem - 1u)) != 0) return fail(h, MPE_ERR_INVALID, "%s: state buffers must be aligned to their element size (got %p)", who, ptr);
+    if ((((uintptr_t)a.actions | (uintptr_t)a.aux) & 3u) != 0) return fail(h, MPE_ERR_INVALID, "%s: actions and aux must be 4-byte aligned", who);
     DeviceScope scope(h->device);
     hipError_t e = scope.status;
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");

@@ -31,7 +31,8 @@ class WorldSpec:
     contact_margin: float = 1e-3
     name: str = ""
     # World.walls (multiagent/core.py:26-42) as dicts {orient 'H'|'V', axis_pos, endpoints (lo, hi), width, hard};
-    # Agent.ghost flags.  Only the physics-only step (SCN_NONE) simulates walls.
+    # Agent.ghost flags.  The physics-only step (SCN_NONE) simulates any walls; simple_predator_prey and
+    # consensus carry their four arena walls; the other built-in scenarios have none.
     walls: list = field(default_factory=list)
     ghost: np.ndarray = None
     # World.collaborative: step returns the summed reward to every agent (multiagent/environment.py:38,103-105)

@@ -528,6 +528,25 @@ def test_misaligned_buffer_is_refused():
     assert b"16-byte aligned" in lib.mpe_last_error(env._h)
 
 
+def test_steps_read_action_slices_of_any_batch_size():
+    """A step may read actions[t] of a pre-generated [T, B, n_act] array: with B = 6 most slices start off a
+    16-byte boundary.  Only output rows need that alignment; the result equals stepping from aligned copies."""
+    import mpe_hip
+    B, T = 6, 5
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    actions = torch.randint(0, 5, (T, B, 3), generator=gen, device="cuda", dtype=torch.int32)
+    assert any(actions[t].data_ptr() % 16 for t in range(T))
+    a = mpe_hip.BatchedEnv("simple_spread", B, dtype=torch.float64)
+    b = mpe_hip.BatchedEnv("simple_spread", B, dtype=torch.float64)
+    a.reset(seed=5)
+    b.reset(seed=5)
+    for t in range(T):
+        oa, ra, _, _ = a.step(actions[t])                   # the slice itself
+        ob, rb, _, _ = b.step(actions[t].clone())           # a fresh (aligned) allocation
+        assert torch.equal(oa, ob) and torch.equal(ra, rb)
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.vel, b.vel)
+
+
 def test_entry_points_leave_the_callers_device_current():
     """The library selects the handle's device for its launches and puts the caller's device back."""
     import mpe_hip
