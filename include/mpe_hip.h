@@ -297,6 +297,24 @@ int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* 
                    mpe_stream_t stream);
 
 /*
+ * mpe_world_step without a handle and without allocating anything.  It has no counterpart in the
+ * reference: it exists for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  mpe_create gives a physics-only handle a
+ * per-entity table from hipMalloc; here that table lives in a static device array inside the
+ * library (MPE_STATIC_SCRATCH_BYTES per GPU, held until the process ends) and is rewritten in full
+ * from `spec` by every call, on `stream`, before the step kernel reads it.  `spec` is a HOST pointer,
+ * read before the call returns, with scenario MPE_SCN_NONE; buffers as in mpe_world_step (env-major
+ * state on `device`).  Limits: MPE_MAX_AGENTS agents, MPE_MAX_LANDMARKS landmarks, MPE_MAX_WALLS
+ * walls, 2^31-1 envs; a larger request is refused with MPE_ERR_INVALID.  The call uses no hipMalloc,
+ * hipFree or host allocation; errors are reported by mpe_last_error(NULL).  All calls on one GPU
+ * share that GPU's array: calls that overlap in time on one GPU (different streams or threads)
+ * race for it; calls on one stream, or otherwise ordered, are safe.
+ */
+#define MPE_STATIC_SCRATCH_BYTES 8192
+int mpe_world_step_static(const MpeSpec* spec, int64_t n_envs, int dtype, int device, const void* u, const void* c,
+                          void* pos, void* vel, void* comm, mpe_stream_t stream);
+
+/*
  * Generalised advantage estimation, the scan the reference's runner applies to a rollout before the
  * policy update (multiagent/backup/runner_old.py:58-80), for all envs at once.  Needs no handle.
  *   rewards, values  float[T][B][A]   what step returned / the value head predicted, per step

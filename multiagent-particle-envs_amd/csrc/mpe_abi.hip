@@ -473,6 +473,28 @@ int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* 
     return MPE_OK;
 }
 
+int mpe_world_step_static(const MpeSpec* spec, int64_t n_envs, int dtype, int device, const void* u, const void* c, void* pos, void* vel,
+                          void* comm, mpe_stream_t stream) {
+    HostSpec s;
+    memset(&s, 0, sizeof(s));
+    const int rc = read_spec(spec, n_envs, dtype, device, s, "mpe_world_step_static");
+    if (rc != MPE_OK) return rc;
+    if (s.scenario != MPE_SCN_NONE) return fail(nullptr, MPE_ERR_INVALID, "mpe_world_step_static: the spec's scenario must be MPE_SCN_NONE");
+    if (n_envs > 0x7fffffffLL) return fail(nullptr, MPE_ERR_INVALID, "mpe_world_step_static: at most 2^31-1 envs");
+    if (!u || !pos || !vel) return fail(nullptr, MPE_ERR_INVALID, "mpe_world_step_static: u, pos and vel must not be NULL");
+    int rows = 0;
+    for (int i = 0; i < s.A; ++i) rows += s.silent[i] ? 0 : s.dim_c;
+    if (rows > 0 && (!c || !comm)) return fail(nullptr, MPE_ERR_INVALID, "mpe_world_step_static: c and comm must not be NULL for a world with speaking agents");
+    DevTable t;
+    fill_table(s, t);
+    DeviceScope scope(device);
+    hipError_t e = scope.status;
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+    e = launch_world_step_static(s, t, device, n_envs, dtype, u, c, pos, vel, comm, rows, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "mpe_world_step_static");
+    return MPE_OK;
+}
+
 int mpe_gae(int device, int mode, int64_t n_envs, int32_t n_agents, int32_t n_steps, const float* rewards, const float* values,
             const uint8_t* dones, const float* last_values, const uint8_t* last_dones, double gamma, double lam, float* adv, float* ret,
             mpe_stream_t stream) {

@@ -112,4 +112,8 @@ bool wave_supported(const HostSpec& s);
 hipError_t launch_wave(const HostSpec& s, const DevTable* table, long long n_envs, int dtype, int mode, const StepArgs& a, hipStream_t st);
 hipError_t launch_world_step(const HostSpec& s, const DevTable* table, long long n_envs, int dtype, const void* u, const void* c,
                              void* pos, void* vel, void* comm, int n_speak_rows, hipStream_t st);
+// World.step with the per-entity table staged in the library's static device array instead of a handle's
+// allocation (mpe_wave.hip); `device` must be current
+hipError_t launch_world_step_static(const HostSpec& s, const DevTable& table, int device, long long n_envs, int dtype, const void* u, const void* c,
+                                    void* pos, void* vel, void* comm, int n_speak_rows, hipStream_t st);
 }  // namespace mpe

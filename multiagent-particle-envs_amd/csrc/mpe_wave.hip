@@ -14,6 +14,10 @@
 //
 // Epilogues: EPI_NONE  -- World.step only; forces and comm actions come in as arrays
 //            EPI_SPREAD -- int actions in, simple_spread observation / reward / benchmark_data out
+#include <string.h>
+
+#include <mutex>
+
 #include "mpe_launch.hpp"
 #include "mpe_math.hpp"
 
@@ -362,6 +366,65 @@ hipError_t launch_world_step(const HostSpec& s, const DevTable* table, long long
     const StepArgs a{nullptr, pos, vel, comm, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
     return dtype == MPE_F64 ? launch_wave_t<double, EPI_NONE, WMODE_STEP>(s, table, B, a, u, c, n_speak_rows, st)
                             : launch_wave_t<float, EPI_NONE, WMODE_STEP>(s, table, B, a, u, c, n_speak_rows, st);
+}
+
+// ---- World.step without a handle and without allocating: the table lives in a static device array ----
+//
+// mpe_create keeps the per-entity table of a wave-per-world handle in memory it gets from hipMalloc.
+// Callers that must not allocate (code under HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc) get the same step with the table in `scratch`, a file-scope device array: every GPU the
+// library runs on holds its own copy of the array, at its own address, until the process ends.  Each
+// call rewrites the whole table (kernel arguments -> scratch, on the caller's stream) before the step
+// kernel reads it, so nothing of an earlier call survives; two calls that overlap on one GPU (different
+// streams) race for the array.
+constexpr size_t SCRATCH_BYTES = MPE_STATIC_SCRATCH_BYTES;
+static_assert(sizeof(DevTable) <= SCRATCH_BYTES && sizeof(DevTable) % 4 == 0, "the per-entity table must fit the static scratch array");
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static void* g_scratch_ptr[SCRATCH_MAX_DEVICES];    // device address of `scratch` on each GPU, resolved on first use
+static std::mutex g_scratch_mutex;
+
+// Address of the CURRENT device's copy of `scratch` (the caller has made `device` current).  In host code
+// the array's name is only a handle for this lookup, never a device address.
+static hipError_t scratch_address(int device, void** out) {
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device] == nullptr) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (ptr == nullptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
+// The table travels as kernel arguments (copied at launch, also under graph capture), a piece at a time:
+// kernel arguments are limited to 4 KiB and the table is a little larger.
+constexpr int PIECE_WORDS = 512;
+struct TablePiece { uint32_t w[PIECE_WORDS]; };
+
+__global__ __launch_bounds__(256) void table_piece_kernel(uint32_t* __restrict__ dst, const TablePiece piece, int n_words) {
+    for (int k = threadIdx.x; k < n_words; k += 256) dst[k] = piece.w[k];
+}
+
+hipError_t launch_world_step_static(const HostSpec& s, const DevTable& table, int device, long long B, int dtype, const void* u, const void* c,
+                                    void* pos, void* vel, void* comm, int n_speak_rows, hipStream_t st) {
+    void* ptr = nullptr;
+    hipError_t e = scratch_address(device, &ptr);
+    if (e != hipSuccess) return e;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&table);
+    const int total = (int)(sizeof(DevTable) / 4);
+    for (int w0 = 0; w0 < total; w0 += PIECE_WORDS) {
+        TablePiece piece;
+        const int n = total - w0 < PIECE_WORDS ? total - w0 : PIECE_WORDS;
+        memcpy(piece.w, src + w0, (size_t)n * 4);
+        hipLaunchKernelGGL(table_piece_kernel, dim3(1), dim3(256), 0, st, static_cast<uint32_t*>(ptr) + w0, piece, n);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return launch_world_step(s, static_cast<const DevTable*>(ptr), B, dtype, u, c, pos, vel, comm, n_speak_rows, st);
 }
 
 }  // namespace mpe

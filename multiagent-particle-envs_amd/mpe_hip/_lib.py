@@ -73,6 +73,8 @@ EXPORTS = {
     # (handle, seed, episode, mask, pos, vel, comm, aux, stream)
     "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
+    # (spec, n_envs, dtype, device, u, c, pos, vel, comm, stream): no handle, no allocation
+    "mpe_world_step_static": (C.c_int, [C.POINTER(MpeSpec), C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
     # (device, mode, n_envs, n_agents, n_steps, rewards, values, dones, last_values, last_dones, gamma, lam, adv, ret, stream)
     "mpe_gae": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 3),
 }
