@@ -262,6 +262,16 @@ int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_
                  const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done,
                  int32_t* info_i, void* info_f, mpe_stream_t stream);
 
+/*
+ * Scenario.post_step alone (simple_predator_prey.py:83-107, collector.py:84-110), what MultiAgentEnv.step
+ * calls as post_step_callback after the observation / reward callbacks (environment.py:107-108): pick-ups,
+ * hand-overs and respawns exactly as mpe_step applies them, for a caller that steps the world and
+ * evaluates the callbacks itself (mpe_world_step + mpe_observe).  Rewrites the landmark rows of pos and
+ * aux (rows 1-2 hold the world's respawn stream, advanced by every respawn).  MPE_ERR_UNSUPPORTED for
+ * scenarios without a post_step.
+ */
+int mpe_post_step(MpeHandle* h, void* pos, int32_t* aux, mpe_stream_t stream);
+
 /* The scenario callbacks on the current state, without stepping: observation for every agent
  * (what MultiAgentEnv.reset returns, environment.py:122-127) and, when rew is not NULL, also
  * reward (environment.py:149-152) and benchmark_data (info_i / info_f, NULL to skip). */

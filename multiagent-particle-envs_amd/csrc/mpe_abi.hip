@@ -441,6 +441,24 @@ int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm
     return run(h, 2, a, stream, "mpe_observe");
 }
 
+int mpe_post_step(MpeHandle* h, void* pos, int32_t* aux, mpe_stream_t stream) {
+    if (!h) return MPE_ERR_INVALID;
+    if (h->spec.scenario != MPE_SCN_PREDATOR_PREY && h->spec.scenario != MPE_SCN_COLLECTOR)
+        return fail(h, MPE_ERR_UNSUPPORTED, "mpe_post_step: only simple_predator_prey and collector define post_step");
+    if (!pos || !aux) return fail(h, MPE_ERR_INVALID, "mpe_post_step: pos and aux must not be NULL");
+    const uintptr_t elem = h->dtype == MPE_F64 ? 8u : 4u;
+    if (((uintptr_t)pos & (elem - 1u)) != 0 || ((uintptr_t)aux & 3u) != 0) return fail(h, MPE_ERR_INVALID, "mpe_post_step: misaligned buffer");
+    DeviceScope scope(h->device);
+    hipError_t e = scope.status;
+    if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
+    StepArgs a{};
+    a.pos = pos;
+    a.aux = aux;
+    e = launch_small(h->spec, h->layout.n_envs, h->dtype, 3, a, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(h, e, "mpe_post_step");
+    return MPE_OK;
+}
+
 int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask, void* pos, void* vel, void* comm,
               int32_t* aux, mpe_stream_t stream) {
     if (!h) return MPE_ERR_INVALID;

@@ -87,7 +87,7 @@ inline double landmark_limit(const HostSpec& s) {
     return (s.scenario == MPE_SCN_TAG || s.scenario == MPE_SCN_WORLD_COMM || s.scenario == MPE_SCN_PREDATOR_PREY) ? 0.9 : 1.0;
 }
 
-// small in-register scenarios (mpe_small.hip); mode: 0 step, 1 rollout, 2 observe
+// small in-register scenarios (mpe_small.hip); mode: 0 step, 1 rollout, 2 observe, 3 Scenario.post_step alone (pos, aux)
 bool small_supported(const HostSpec& s);
 hipError_t launch_small(const HostSpec& s, long long n_envs, int dtype, int mode, const StepArgs& a, hipStream_t st);
 

@@ -588,6 +588,34 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     }
 }
 
+// Scenario.post_step alone, for a caller that runs it as MultiAgentEnv's post_step_callback between its
+// own steps (environment.py:107-108): one lane per world applies the scenario's pick-up / hand-over /
+// respawn rules to the landmark positions and the aux state, exactly as the fused step does.
+template <typename T, class Cfg>
+__global__ __launch_bounds__(64) void post_step_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, T* __restrict__ pos_g, int* __restrict__ aux_g) {
+    constexpr int A = Cfg::A, E = Cfg::E, NX = Cfg::N_AUX;
+    const long long B = p.n_envs;
+    const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    V2<T> pos[E];
+    int aux[NX > 0 ? NX : 1] = {0};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        pos[e].x = pos_g[(long long)(2 * e) * B + b];
+        pos[e].y = pos_g[(long long)(2 * e + 1) * B + b];
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) aux[k] = aux_g[(long long)k * B + b];
+    Cfg::post_step(pos, aux, p, (unsigned long long)b);
+#pragma unroll
+    for (int e = A; e < E; ++e) {
+        pos_g[(long long)(2 * e) * B + b] = pos[e].x;
+        pos_g[(long long)(2 * e + 1) * B + b] = pos[e].y;
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) aux_g[(long long)k * B + b] = aux[k];
+}
+
 // ------------------------------------------------------------------------------------------
 template <typename T, class Cfg>
 static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n_envs) {
@@ -663,8 +691,22 @@ static hipError_t launch_cfg(const HostSpec& s, long long B, int mode, const Ste
     return hipGetLastError();
 }
 
+template <typename T, class Cfg>
+static hipError_t launch_post_step(const HostSpec& s, long long B, const StepArgs& a, hipStream_t st) {
+    const auto p = make_params<T, Cfg>(s, B);
+    hipLaunchKernelGGL((post_step_kernel<T, Cfg>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, p, (T*)a.pos, a.aux);
+    return hipGetLastError();
+}
+
+enum { MODE_POST_STEP = 3 };     // launch_small only: Scenario.post_step alone (a.pos, a.aux)
+
 template <typename T>
 hipError_t launch_small_t(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
+    if (mode == MODE_POST_STEP) {
+        if (s.scenario == MPE_SCN_PREDATOR_PREY) return launch_post_step<T, PredatorPreyCfg>(s, B, a, st);
+        if (s.scenario == MPE_SCN_COLLECTOR) return launch_post_step<T, CollectorCfg>(s, B, a, st);
+        return hipErrorInvalidValue;
+    }
     const bool clamp = s.any_speed_limit();
     switch (s.scenario) {
         case MPE_SCN_SPREAD:

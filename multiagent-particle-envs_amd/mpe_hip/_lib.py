@@ -70,6 +70,7 @@ EXPORTS = {
     "mpe_episodes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32] + [C.c_void_p] * 10 + [C.c_void_p]),
     # (handle, pos, vel, comm, aux, obs, rew, info_i, info_f, stream)
     "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]),
+    "mpe_post_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     # (handle, seed, episode, mask, pos, vel, comm, aux, stream)
     "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),

@@ -194,6 +194,12 @@ class BatchedEnv:
             self._episode += 1
         return out
 
+    def post_step(self):
+        """Scenario.post_step alone (simple_predator_prey, collector): pick-ups, hand-overs and respawns on the
+        current state, as ``step`` applies them after the callbacks.  Rewrites landmark positions and ``aux``."""
+        p = self._p
+        _lib.check(self._h, self._lib.mpe_post_step(self._h, p["pos"], p["aux"], self._stream()))
+
     # ------------------------------------------------------------------
     def set_state(self, pos, vel, comm=None, goal=None):
         """Inject a state given env-major: pos [B, E, 2], vel [B, A, 2], comm [B, S*dim_c], and the landmark

@@ -44,9 +44,16 @@ class MultiAgentEnv:
         # a built-in scenario drives the fused kernel when it owns every callback that was passed
         owner = getattr(reward_callback, "__self__", None)
         cbs = [cb for cb in (reset_callback, reward_callback, observation_callback, info_callback) if cb is not None]
-        self._scenario = owner if isinstance(owner, HipScenario) and all(getattr(cb, "__self__", None) is owner for cb in cbs) \
-            and observation_callback is not None and done_callback is None and not world.scripted_agents \
-            and owner.fused_step and post_step_callback is None else None
+        fusable = isinstance(owner, HipScenario) and all(getattr(cb, "__self__", None) is owner for cb in cbs) \
+            and observation_callback is not None and done_callback is None and not world.scripted_agents and owner.fused_step
+        if fusable and owner.dynamic:
+            # the fused kernel of a scenario with a post_step always applies it: usable exactly when the
+            # scenario's own (device) post_step is the post_step_callback
+            fusable = getattr(post_step_callback, "__self__", None) is owner and \
+                getattr(post_step_callback, "__func__", None) is HipScenario.post_step
+        elif fusable:
+            fusable = post_step_callback is None
+        self._scenario = owner if fusable else None
 
         self.action_space, self.observation_space = [], []
         for agent in self.agents:
@@ -98,8 +105,8 @@ class MultiAgentEnv:
             info_n["r{}".format(i)] = r                                        # environment.py:100
         if self.shared_reward:
             reward_n = [np.sum(reward_n)] * self.n                             # environment.py:103-105
-        if self.post_step_callback is not None:
-            self.post_step_callback(self.world, self.np_random)
+        if self.post_step_callback is not None and not (self._scenario is not None and self._scenario.dynamic):
+            self.post_step_callback(self.world, self.np_random)         # (the fused step of a dynamic scenario already applied it)
         return obs_n, reward_n, bool(any(done_n)), info_n                      # environment.py:110-115
 
     # ------------------------------------------------------------------
@@ -148,10 +155,16 @@ class MultiAgentEnv:
         env.step(torch.tensor([flat], dtype=torch.int32))
         world.t += 1
         world.unpack_state(*env.get_state())
+        after = getattr(world, "after_step", None)      # new_core worlds: history and distance cache of the new state
+        if after is not None:
+            after()
         sc.store(world, env)
         obs_n = [sc.observation(a, world) for a in self.agents]
         reward_n = [sc.reward(a, world) for a in self.agents]
         info_list = [sc.benchmark_data(a, world) if self.info_callback is not None else {} for a in self.agents]
+        if sc.dynamic:
+            # the kernel ran post_step after the callbacks: take over its pick-ups, hand-overs and respawns
+            sc._absorb_from(world, env, self.np_random)
         return obs_n, reward_n, info_list
 
     def _get_obs(self, agent):

@@ -55,6 +55,10 @@ class World(_CoreWorld):
     def step(self):
         """new_core.py:188-205."""
         super().step()
+        self.after_step()
+
+    def after_step(self):
+        """What new_core.py:204-205,252-254 do once the new state is known: slide the histories, refresh the cache."""
         for e in self.entities:
             if e.movable and hasattr(e.state, "p_his_pos"):
                 e.state.p_his_pos = np.vstack([e.state.p_his_pos[1:], e.state.p_pos])

@@ -49,6 +49,7 @@ class HipScenario(BaseScenario):
     has_info = True          # the scenario defines benchmark_data
     fused_info = None        # ask the kernel for info_i / info_f (None: when has_info)
     fused_step = True        # MultiAgentEnv.step may run the whole step as one fused launch
+    dynamic = False          # the scenario has a post_step (the kernel applies it: int state in aux, landmarks move)
 
     def __init__(self):
         self._env = None        # (signature, BatchedEnv)
@@ -76,7 +77,7 @@ class HipScenario(BaseScenario):
     @staticmethod
     def _key(pos, vel, comm, goal):
         return pos.tobytes() + vel.tobytes() + (comm.tobytes() if comm is not None else b"") + \
-            bytes([255] if goal is None else np.atleast_1d(goal).tolist())
+            (b"-" if goal is None else np.asarray(goal, np.int64).tobytes())
 
     @staticmethod
     def _outputs(env):
@@ -106,6 +107,30 @@ class HipScenario(BaseScenario):
             env.observe(score=True)
             self._cache = (key,) + self._outputs(env)
         return self._cache
+
+    # -- post_step on the device ------------------------------------------
+    def absorb(self, world, aux, landmark_pos, np_random=None):
+        """Map what the kernel's post_step left (aux rows [n_aux], landmark positions [L, 2]) back onto
+        the world's objects.  Dynamic scenarios override it."""
+        raise NotImplementedError()
+
+    def _absorb_from(self, world, env, np_random):
+        A = len(world.agents)
+        pos, _, _ = env.get_state()
+        self.absorb(world, [int(x) for x in env.aux[:, 0].cpu().numpy()], pos[0, A:], np_random)
+        self._cache = None
+
+    def post_step(self, world, np_random=None):
+        """Scenario.post_step (called by MultiAgentEnv as post_step_callback, environment.py:107-108), run by
+        the ``mpe_post_step`` kernel on the one-world batch: the rules themselves live in the kernel only.  A
+        generator passed as ``np_random`` supplies the values of a respawn (as the reference's collector draws
+        them from its argument); without one they come from the world's counter-based device stream."""
+        if not self.dynamic:
+            raise AttributeError("scenario %r defines no post_step" % self.hip_name)
+        env = self.fused_env(world)
+        self.load_state(world, env)
+        env.post_step()
+        self._absorb_from(world, env, np_random)
 
     # -- the plugin callbacks --------------------------------------------
     def observation(self, agent, world):

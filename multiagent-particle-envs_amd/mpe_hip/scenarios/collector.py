@@ -3,9 +3,13 @@ type (multiagent/scenarios/collector.py, on the physics of multiagent/new_core.p
 
 The batched form (``BatchedEnv("collector", ...)``) runs the whole step, ``post_step`` included, in one
 kernel.  This single-world plugin keeps the reference's contract: the env calls ``post_step`` only if
-it was given as ``post_step_callback``, so the step is World.step on the GPU, the callbacks of all
-agents through one ``mpe_observe`` launch, and ``post_step`` below on the host objects.
+it was given as ``post_step_callback``.  Given, the whole step is one fused ``mpe_step`` launch; not given,
+the step is World.step on the GPU and the callbacks of all agents through one ``mpe_observe`` launch.
+``post_step`` itself is always the kernel's (``mpe_post_step`` when called on its own): this file only maps
+the kernel's state word onto the objects.
 """
+import zlib
+
 import numpy as np
 
 from .. import _lib
@@ -17,7 +21,7 @@ class Scenario(HipScenario):
     scenario_id = _lib.SCN_COLLECTOR
     hip_name = "collector"
     obs_dtype = np.float32       # collector.py:295
-    fused_step = False
+    dynamic = True
 
     def make_world(self):
         world = World()
@@ -74,43 +78,43 @@ class Scenario(HipScenario):
             lm.state.p_vel = np.zeros(world.dim_p)
             lm.alive = True
         world.calculate_distances()
+        # the device's respawn stream of this episode, keyed by the drawn state (no extra draw from rng)
+        world.respawn_stream = [zlib.crc32(np.array([e.state.p_pos for e in world.entities]).tobytes()) & 0x7fffffff, 0]
 
     def is_collision(self, agent1, agent2, world):
         return bool(world.cached_dist_mag[agent1.i, agent2.i] < agent1.size + agent2.size)
 
-    def post_step(self, world, np_random=None):
-        """collector.py:84-110."""
-        rng = np_random if np_random is not None else np.random
-        for l in world.landmarks:
-            if l.alive:
-                for a in self.collectors(world):
-                    if a.holding is None and self.is_collision(l, a, world):
-                        l.alive, a.holding = False, l.type
-                        a.color = 0.85 * l.color
-                        l.state.p_pos = np.array([-0., -0.])
-                        l.visible = False
-                        break
-            elif rng.uniform() <= l.respawn_prob:
-                l.state.p_pos = rng.uniform(low=-0.95, high=0.95, size=world.dim_p)
-                l.type = int(rng.choice(world.treasure_types))
-                l.color = world.treasure_colors[l.type]
-                l.alive, l.visible = True, True
-        for a in self.collectors(world):
-            if a.holding is not None:
-                for d in self.deposits(world):
-                    if d.d_i == a.holding and self.is_collision(a, d, world):
-                        a.holding = None
-                        a.color = np.array([0.85, 0.85, 0.85], dtype=np.float32)
+    # post_step (collector.py:84-110) is HipScenario.post_step: the mpe_post_step kernel applies the
+    # pick-up / respawn / deposit rules; absorb() below only copies its result onto the objects.
+    def absorb(self, world, aux, landmark_pos, np_random=None):
+        word = aux[0]
+        for l, t in enumerate(world.landmarks):
+            was_alive = t.alive
+            t.alive = t.visible = bool(word >> (18 + l) & 1)
+            t.type = int(word >> (12 + l) & 1)
+            t.state.p_pos = np.array(landmark_pos[l])
+            if t.alive and not was_alive and np_random is not None:
+                # the caller's generator supplies the respawn, in the reference's order of draws
+                np_random.uniform()                                 # the respawn_prob test (1.0: always passes)
+                t.state.p_pos = np_random.uniform(low=-0.95, high=0.95, size=world.dim_p)
+                t.type = int(np_random.choice(world.treasure_types))
+            t.color = world.treasure_colors[t.type]
+        for k, a in enumerate(self.collectors(world)):
+            held = word >> (2 * k) & 3
+            a.holding = None if held == 0 else held - 1
+            a.color = np.array([0.85, 0.85, 0.85]) if a.holding is None else 0.85 * world.treasure_colors[a.holding]     # display only
+        world.respawn_stream = [aux[1], aux[2]]
 
     def goal_index(self, world):
-        """The state word the kernel's callbacks read (2 bits per collector: 0 nothing, 1 + type held; bit
-        12+l: type of treasure l; bit 18+l: treasure l alive) and an idle respawn stream."""
+        """The aux rows of the one-world batch: the state word the kernel reads (2 bits per collector: 0
+        nothing, 1 + type held; bit 12+l: type of treasure l; bit 18+l: treasure l alive), then key and
+        position of the world's respawn stream."""
         w = 0
         for k, a in enumerate(self.collectors(world)):
             w |= (0 if a.holding is None else 1 + int(a.holding)) << (2 * k)
         for l, t in enumerate(world.landmarks):
             w |= (int(t.type) & 1) << (12 + l) | int(bool(t.alive)) << (18 + l)
-        return [w, 0, 0]
+        return [w] + list(getattr(world, "respawn_stream", [0, 0]))
 
     @staticmethod
     def _key(pos, vel, comm, goal):

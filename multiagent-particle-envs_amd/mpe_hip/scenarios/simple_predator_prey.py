@@ -3,11 +3,14 @@ their leader; forests hide agents, walls close the arena (multiagent/scenarios/s
 on the physics of multiagent/new_core.py).
 
 The batched form (``BatchedEnv("simple_predator_prey", ...)``) runs the whole step, ``post_step``
-included, in one kernel.  This single-world plugin keeps the reference's contract instead: the env
-calls ``post_step`` only if it was given as ``post_step_callback`` (``make_env`` does not pass it),
-so the step is World.step on the GPU, the callbacks through one ``mpe_observe`` launch, and
-``post_step`` below on the host objects.
+included, in one kernel.  This single-world plugin keeps the reference's contract: the env calls
+``post_step`` only if it was given as ``post_step_callback`` (``make_env`` does not pass it).  Given, the
+whole step is one fused ``mpe_step`` launch; not given, the step is World.step on the GPU and the
+callbacks through one ``mpe_observe`` launch.  ``post_step`` itself is always the kernel's (``mpe_post_step``
+when called on its own): this file only maps the kernel's state word onto the objects.
 """
+import zlib
+
 import numpy as np
 
 from .. import _lib
@@ -19,7 +22,7 @@ class Scenario(HipScenario):
     scenario_id = _lib.SCN_PREDATOR_PREY
     hip_name = "simple_predator_prey"
     obs_dtype = np.float32       # simple_predator_prey.py:349
-    fused_step = False
+    dynamic = True
 
     def make_world(self):
         world = World()
@@ -85,6 +88,8 @@ class Scenario(HipScenario):
             while any(touches(f, o) for o in world.barrier + world.forests):
                 f.state.p_pos = rng.uniform(-0.9, +0.9, world.dim_p)
         world.calculate_distances()
+        # the device's respawn stream of this episode, keyed by the drawn state (no extra draw from rng)
+        world.respawn_stream = [zlib.crc32(np.array([e.state.p_pos for e in world.entities]).tobytes()) & 0x7fffffff, 0]
 
     def is_collision(self, agent1, agent2, world):
         return bool(world.cached_dist_mag[agent1.i, agent2.i] < agent1.size + agent2.size)
@@ -95,34 +100,24 @@ class Scenario(HipScenario):
     def adversaries(self, world):
         return [a for a in world.agents if a.adversary]
 
-    def post_step(self, world, np_random=None):
-        """simple_predator_prey.py:83-107 (the reference draws respawns from the global numpy generator;
-        a generator passed as post_step_callback's second argument is used when given)."""
-        rng = np_random if np_random is not None else np.random
-        leaders = [g for g in self.good_agents(world) if g.leader]
-        members = [g for g in self.good_agents(world) if not g.leader]
-        for f in world.foods:
-            if f.alive:
-                for m in members:
-                    if not m.holding and self.is_collision(f, m, world):
-                        f.alive, m.holding = False, True
-                        m.color = np.array([0.55, 0.55, 0.85])
-                        f.state.p_pos = np.array([-999., -999.])
-                        break
-            elif rng.uniform() <= f.respawn_prob:
-                f.state.p_pos = rng.uniform(low=-0.95, high=0.95, size=world.dim_p)
-                f.alive = True
-        for m in members:
-            if m.holding:
-                for l in leaders:
-                    if self.is_collision(m, l, world):
-                        m.holding = False
-                        l.color = m.color - np.array([0.35, 0.35, 0.35])
-                        m.color = np.array([0.85, 0.85, 0.85], dtype=np.float32)
+    # post_step (simple_predator_prey.py:83-107) is HipScenario.post_step: the mpe_post_step kernel applies
+    # the pick-up / respawn / hand-over rules; absorb() below only copies its result onto the objects.
+    def absorb(self, world, aux, landmark_pos, np_random=None):
+        flags = aux[0]
+        for k, f in enumerate(world.foods):
+            was_alive, f.alive = f.alive, bool(flags >> k & 1)
+            f.state.p_pos = np.array(landmark_pos[1 + k])           # landmarks: barrier, foods, forests
+            if f.alive and not was_alive and np_random is not None:
+                np_random.uniform()                                 # the respawn_prob test (1.0: always passes)
+                f.state.p_pos = np_random.uniform(low=-0.95, high=0.95, size=world.dim_p)
+        for k, m in enumerate(world.agents[4:]):
+            m.holding = bool(flags >> (3 + k) & 1)
+            m.color = np.array([0.55, 0.55, 0.85] if m.holding else [0.85, 0.85, 0.85])     # display only
+        world.respawn_stream = [aux[1], aux[2]]
 
     def goal_index(self, world):
-        """The flags the kernel's callbacks read (bit f: food f alive, bit 3+k: member k holds food) and an
-        idle respawn stream."""
+        """The aux rows of the one-world batch: the flags the kernel reads (bit f: food f alive, bit 3+k:
+        member k holds food), then key and position of the world's respawn stream."""
         flags = sum(int(bool(f.alive)) << k for k, f in enumerate(world.foods))
         flags |= sum(int(bool(m.holding)) << (3 + k) for k, m in enumerate(world.agents[4:]))
-        return [flags, 0, 0]
+        return [flags] + list(getattr(world, "respawn_stream", [0, 0]))

@@ -216,16 +216,20 @@ def test_rollout_and_episode_equal_stepping(dtype):
     assert torch.equal(e1.aux, e2.aux)
 
 
-def test_plugin_env_with_post_step_replays_the_reference():
-    """The single-world plugin (GPU step + mpe_observe callbacks + host post_step) through MultiAgentEnv
-    with post_step as post_step_callback, on an env of the fixture in which no treasure respawns."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_plugin_env_with_post_step_replays_the_reference(fused):
+    """The single-world plugin through MultiAgentEnv with post_step as post_step_callback (its rules run in the
+    kernels only), on an env of the fixture in which no treasure respawns."""
     import mpe_hip
     from mpe_hip.scenarios import load
     g = load_golden(CASE)
     sc = load(CASE + ".py").Scenario()
     world = sc.make_world()
-    env = mpe_hip.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data, post_step_callback=sc.post_step)
-    assert env._scenario is None and [s.shape[0] for s in env.observation_space] == list(g["obs_dims"])
+    # the scenario's own post_step as callback: one fused mpe_step launch per step; wrapped (as a caller with its
+    # own hook would): World.step + mpe_observe + the mpe_post_step kernel.  Either way no rule runs on the host.
+    post = sc.post_step if fused else (lambda w, rng: sc.post_step(w, rng))
+    env = mpe_hip.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data, post_step_callback=post)
+    assert (env._scenario is sc) == fused and [s.shape[0] for s in env.observation_space] == list(g["obs_dims"])
     env.seed(0)
     env.reset()
     b = [k for k in range(g["pos0"].shape[0]) if g["alive0"][k].all() and g["alive"][:, k].all() and (g["holding0"][k] >= 0).any()][0]
@@ -248,3 +252,52 @@ def test_plugin_env_with_post_step_replays_the_reference():
         assert _close(rew_n, g["rew"][t, b], 1e-9, 1e-12) and done is False
         assert [tuple(x) for x in info["n"]] == [tuple(x) for x in g["info"][t, b]]
         assert [-1 if a.holding is None else a.holding for a in world.agents[:6]] == list(g["holding"][t, b])
+
+
+def _plugin_env(g, b, fused, seed):
+    import mpe_hip
+    from mpe_hip.scenarios import load
+    sc = load(CASE + ".py").Scenario()
+    world = sc.make_world()
+    post = sc.post_step if fused else (lambda w, rng: sc.post_step(w, rng))
+    env = mpe_hip.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data, post_step_callback=post)
+    env.seed(seed)
+    env.reset()
+    for i, e in enumerate(world.entities):
+        e.state.p_pos = g["pos0"][b, i].copy()
+        if i < env.n:
+            e.state.p_vel = g["vel0"][b, i].copy()
+    for k, a in enumerate(world.agents[:6]):
+        a.holding = None if g["holding0"][b, k] < 0 else int(g["holding0"][b, k])
+    for l, t in enumerate(world.landmarks):
+        t.type, t.alive = int(g["ttype0"][b, l]), bool(g["alive0"][b, l])
+    world.calculate_distances()
+    return env, world
+
+
+def test_plugin_env_respawns_agree_between_the_fused_step_and_the_post_step_kernel():
+    """An env of the fixture in which treasures are taken and respawn: the fused step (post_step inside mpe_step) and
+    the split step (mpe_world_step, mpe_observe, mpe_post_step) leave identical worlds, respawn values drawn from the
+    env's generator in the reference's order; up to the first respawn both are the reference's trajectory."""
+    g = load_golden(CASE)
+    taken = [k for k in range(g["pos0"].shape[0]) if g["alive0"][k].all() and not g["alive"][:, k].all()]
+    assert taken
+    b = taken[0]
+    first_dead = int(np.argmax(~g["alive"][:, b].all(axis=1)))        # the step whose post_step takes the first treasure
+    envs = [_plugin_env(g, b, fused, seed=7) for fused in (True, False)]
+    off = np.concatenate([[0], np.cumsum(g["obs_dims"])])
+    respawned = False
+    for t in range(25):
+        outs = [env.step([int(x) for x in g["actions"][t, b]]) for env, _ in envs]
+        (o1, r1, _, i1), (o2, r2, _, i2) = outs
+        assert all(np.array_equal(x, y) for x, y in zip(o1, o2)) and r1 == r2 and i1["n"] == i2["n"], t
+        w1, w2 = envs[0][1], envs[1][1]
+        assert all(np.array_equal(e1.state.p_pos, e2.state.p_pos) for e1, e2 in zip(w1.entities, w2.entities)), t
+        assert [a.holding for a in w1.agents[:6]] == [a.holding for a in w2.agents[:6]]
+        assert [(x.alive, x.type) for x in w1.landmarks] == [(x.alive, x.type) for x in w2.landmarks]
+        assert w1.respawn_stream == w2.respawn_stream
+        if t <= first_dead + 1:       # the respawned treasure is first seen by the step after the next
+            for i in range(envs[0][0].n):
+                assert _close(o1[i], g["obs"][t, b, off[i]:off[i + 1]], 1e-9, 1e-12), (t, i)
+        respawned = respawned or w1.respawn_stream[1] > 0
+    assert respawned

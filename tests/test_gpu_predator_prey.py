@@ -238,16 +238,20 @@ def test_step_auto_restarts_flags_and_stream():
     assert torch.equal(env.aux, ref.aux) and torch.equal(env.pos, ref.pos) and torch.equal(obs, ref.obs)
 
 
-def test_plugin_env_with_post_step_replays_the_reference():
-    """The single-world plugin: GPU step + mpe_observe callbacks + host post_step, through MultiAgentEnv
-    with post_step as post_step_callback.  Without a respawn in the replayed env the trajectory is the reference's."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_plugin_env_with_post_step_replays_the_reference(fused):
+    """The single-world plugin through MultiAgentEnv with post_step as post_step_callback (its rules run in the
+    kernels only).  Without a respawn in the replayed env the trajectory is the reference's."""
     import mpe_hip
     from mpe_hip.scenarios import load
     g = load_golden(CASE)
     sc = load(CASE + ".py").Scenario()
     world = sc.make_world()
-    env = mpe_hip.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data, post_step_callback=sc.post_step)
-    assert env._scenario is None and [s.shape[0] for s in env.observation_space] == list(g["obs_dims"])
+    # the scenario's own post_step as callback: one fused mpe_step launch per step; wrapped (as a caller with its
+    # own hook would): World.step + mpe_observe + the mpe_post_step kernel.  Either way no rule runs on the host.
+    post = sc.post_step if fused else (lambda w, rng: sc.post_step(w, rng))
+    env = mpe_hip.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data, post_step_callback=post)
+    assert (env._scenario is sc) == fused and [s.shape[0] for s in env.observation_space] == list(g["obs_dims"])
     env.seed(0)
     env.reset()
     b = 9       # member 1 holds food next to its leader and hands it over; no food is eaten
