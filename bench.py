@@ -11,8 +11,8 @@ env reset on device at each episode boundary.  Envs shard by index across GPUs w
 collective (weak scaling: the per-GPU batch is fixed).
 
 Launch modes (--mode):
-  rollout  one mpe_episode launch per 25-step episode: on-device reset + 25 steps (default: the
-           headline number)
+  rollout  one mpe_episode launch per 25-step episode: on-device reset, the reset state's observation and
+           25 steps (default: the headline number)
   step     one mpe_step launch per step, issued eagerly from Python (host-bound)
   graph    one mpe_step launch per step, the 25 launches of an episode replayed as one hipGraph
            (what an RL loop with a captured policy between steps would issue)
@@ -105,12 +105,13 @@ def stored_traffic(key):
 #                   writes agent pos+vel 4A*s, obs obs_total*s, rewards A*s, done 1
 #   rollout launch: state is read once and written once per launch of EPISODE steps, so per
 #                   env-step only actions are read and obs, rewards, done written.
-#   episode launch: as rollout, but the initial state is drawn on the device, not read.
-def algorithmic_bytes(A, L, n_act, obs_total, s, steps_per_launch, reads_state=True):
+#   episode launch: as rollout, but the initial state is drawn on the device, not read, and the
+#                   observation of the reset state (what env.reset() returns) is written once per episode.
+def algorithmic_bytes(A, L, n_act, obs_total, s, steps_per_launch, reads_state=True, reset_obs=False):
     state_rd = (4 * A * s + 2 * L * s) if reads_state else 0
     state_wr = 4 * A * s
     per_step = 4 * n_act + obs_total * s + A * s + 1
-    return per_step + (state_rd + state_wr) / float(steps_per_launch)
+    return per_step + (state_rd + state_wr + (obs_total * s if reset_obs else 0)) / float(steps_per_launch)
 
 
 def cpu_baseline(seconds=12.0):
@@ -353,7 +354,8 @@ def main():
                 elif not rec:
                     open_pair = None
                 # mpe_episode: on-device reset of every env + n steps in one launch
-                outs[n] = env.rollout(actions[:n], outs.get(n), reset_seed=1234 + first_env, episodes=k_ep)
+                # (with the reset state's observation: everything "obs = env.reset(); 25 x env.step(a)" produces)
+                outs[n] = env.rollout(actions[:n], outs.get(n), reset_seed=1234 + first_env, episodes=k_ep, obs0=True)
                 last["out"] = outs[n]
                 if rec and launches % EVENT_GROUP == EVENT_GROUP - 1 and open_pair is not None:
                     e1 = torch.cuda.Event(enable_timing=True)
@@ -424,7 +426,7 @@ def main():
     lo = env.layout
     # an episode's state write-back is once per launch; every episode of a launch is counted as if it wrote it
     bytes_env_step = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, EPISODE if args.mode == "rollout" else 1,
-                                       reads_state=args.mode != "rollout")
+                                       reads_state=args.mode != "rollout", reset_obs=args.mode == "rollout")
     bytes_launch = bytes_env_step * B * avg_steps
     achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
 
@@ -463,8 +465,8 @@ def main():
             "config": {"workload": "%s A=%d L=%d, %d envs/GPU, %d-step episodes, uniform random int actions, on-device reset each episode"
                                    % (args.scenario, A, env.n_landmarks, B, EPISODE),
                        "envs_per_gpu": B, "global_envs": world * B, "episode_steps": EPISODE,
-                       "launch": {"rollout": ("mpe_episode (on-device reset + %d steps) per launch" % EPISODE) if K == 1 else
-                                             ("mpe_episodes: %d x (on-device reset + %d steps) per launch" % (K, EPISODE)), "step": "mpe_step, 1 step/launch, eager",
+                       "launch": {"rollout": ("mpe_episode (on-device reset, its observation, %d steps) per launch" % EPISODE) if K == 1 else
+                                             ("mpe_episodes: %d x (on-device reset, its observation, %d steps) per launch" % (K, EPISODE)), "step": "mpe_step, 1 step/launch, eager",
                                   "graph": "mpe_step, 1 step/launch, %d launches per hipGraph replay" % EPISODE}[args.mode],
                        "timed_region": "the %d-step request repeated %d times between one pair of barrier + synchronize" % (args.steps, plan["repeats"]),
                        "parallelism": "env-index shards, no data-path collective"},

@@ -220,7 +220,7 @@ int mpe_step(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* c
  * mpe_reset(h, seed, episode_count[b], ...), so obs holds the first observation of the new episode
  * (rew and info still describe the step that ended the old one).  All four bookkeeping arrays are
  * caller-owned device buffers, zero-initialised by the caller before the first episode.
- * Not available for consensus (MPE_ERR_UNSUPPORTED): reset it with mpe_reset or run mpe_episode.
+ * (consensus: the reset also refills the history ring with the fresh state.)
  */
 int mpe_step_auto(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux,
                   void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t* step_count,
@@ -242,12 +242,13 @@ int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void
  * One whole episode in one launch: Scenario.reset_world for every env (the draws of
  * mpe_reset(h, seed, episode, NULL, ...)) followed by n_steps MultiAgentEnv.step calls as in
  * mpe_rollout.  pos / vel / comm need not be initialised; they hold the final state on return.
- * The observation of the freshly reset state is not produced (call mpe_reset + mpe_observe +
- * mpe_rollout when the policy needs it).
+ * obs0 T[B][obs_total] (NULL to skip) receives the observation of the freshly reset state, the list
+ * MultiAgentEnv.reset returns (environment.py:122-127), so that the launch does everything the loop
+ * "obs = env.reset(); 25 x env.step(a)" does.
  */
 int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos,
                 void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done, int32_t* info_i,
-                void* info_f, int32_t n_steps, mpe_stream_t stream);
+                void* info_f, void* obs0, int32_t n_steps, mpe_stream_t stream);
 
 /*
  * n_episodes consecutive episodes in one launch: as mpe_episode(h, seed, first_episode + k, ...) for k = 0 ..
@@ -255,12 +256,12 @@ int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* ac
  * n_episodes * steps_per_episode entries, episode after episode.  What the benchmark loop "reset, 25 random
  * steps, repeat" issues, without a launch boundary between the episodes (a launch starts with draws and
  * action fetches during which nothing is stored, and ends with a tail of late waves; inside one launch the
- * waves drift apart and fill both).  Scenarios of the in-register kernels only (MpeLayout.state_env_major
- * == 0, not consensus): MPE_ERR_UNSUPPORTED otherwise unless n_episodes == 1.
+ * waves drift apart and fill both).  obs0 T[n_episodes][B][obs_total] (NULL to skip): the observation
+ * of every episode's reset state.
  */
 int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_episodes, int32_t steps_per_episode,
                  const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done,
-                 int32_t* info_i, void* info_f, mpe_stream_t stream);
+                 int32_t* info_i, void* info_f, void* obs0, mpe_stream_t stream);
 
 /*
  * Scenario.post_step alone (simple_predator_prey.py:83-107, collector.py:84-110), what MultiAgentEnv.step

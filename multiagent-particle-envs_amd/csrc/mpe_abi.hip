@@ -358,15 +358,15 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
     if (!a.pos || !a.vel || !a.obs) return fail(h, MPE_ERR_INVALID, "%s: pos, vel and obs must not be NULL", who);
     if ((h->layout.n_speakers > 0 || h->layout.n_hist_rows > 0) && !a.comm)
         return fail(h, MPE_ERR_INVALID, "%s: comm must not be NULL for a scenario with speaking agents or a history", who);
-    if (h->spec.scenario == MPE_SCN_CONSENSUS && (a.au.step_count != nullptr || a.info_i != nullptr))
-        return fail(h, MPE_ERR_UNSUPPORTED, "%s: consensus has neither mpe_step_auto nor benchmark outputs", who);
+    if (h->spec.scenario == MPE_SCN_CONSENSUS && a.info_i != nullptr)
+        return fail(h, MPE_ERR_UNSUPPORTED, "%s: consensus has no benchmark outputs (its benchmark_data is constant)", who);
     if (mode != 2 && (!a.actions || !a.rew || !a.done)) return fail(h, MPE_ERR_INVALID, "%s: actions, rew and done must not be NULL", who);
     if (mode == 1 && a.n_steps < 1) return fail(h, MPE_ERR_INVALID, "%s: n_steps must be >= 1", who);
     if (a.info_f && !a.info_i) return fail(h, MPE_ERR_INVALID, "%s: info_f requires info_i", who);
     if (a.info_i && h->layout.n_info_i == 0) return fail(h, MPE_ERR_INVALID, "%s: this scenario has no benchmark_data; info_i must be NULL", who);
     if (h->layout.n_aux > 0 && !a.aux) return fail(h, MPE_ERR_INVALID, "%s: aux must not be NULL for a scenario with a goal landmark", who);
     // output rows leave the kernels as 16-byte vectors; actions and state are read and written one element at a time
-    const void* outs[] = {a.obs, a.rew, a.done, a.info_i, a.info_f};
+    const void* outs[] = {a.obs, a.rew, a.done, a.info_i, a.info_f, a.obs0};
     for (const void* ptr : outs)
         if (((uintptr_t)ptr & 15u) != 0) return fail(h, MPE_ERR_INVALID, "%s: every output buffer must be 16-byte aligned (got %p)", who, ptr);
     const uintptr_t elem = h->dtype == MPE_F64 ? 8u : 4u;
@@ -412,23 +412,23 @@ int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void
 }
 
 int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux,
-                void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f, int32_t n_steps, mpe_stream_t stream) {
+                void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f, void* obs0, int32_t n_steps, mpe_stream_t stream) {
     StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_steps};
     a.aux = aux;
+    a.obs0 = obs0;
     if (h) a.reset = ResetArgs{1, seed, episode, landmark_limit(h->spec)};
     return run(h, 1, a, stream, "mpe_episode");
 }
 
 int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_episodes, int32_t steps_per_episode, const int32_t* actions,
                  void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done, int32_t* info_i, void* info_f,
-                 mpe_stream_t stream) {
+                 void* obs0, mpe_stream_t stream) {
     if (!h) return MPE_ERR_INVALID;
     if (n_episodes < 1 || steps_per_episode < 1) return fail(h, MPE_ERR_INVALID, "mpe_episodes: n_episodes and steps_per_episode must be >= 1");
     if ((long long)n_episodes * steps_per_episode > 0x7fffffffLL) return fail(h, MPE_ERR_INVALID, "mpe_episodes: too many steps");
-    if (n_episodes > 1 && (h->use_wave || h->spec.scenario == MPE_SCN_CONSENSUS))
-        return fail(h, MPE_ERR_UNSUPPORTED, "mpe_episodes: this scenario's kernel runs one episode per launch");
     StepArgs a{actions, pos, vel, comm, obs, rew, done, info_i, info_f, n_episodes * steps_per_episode};
     a.aux = aux;
+    a.obs0 = obs0;
     a.reset = ResetArgs{1, seed, first_episode, landmark_limit(h->spec), n_episodes > 1 ? steps_per_episode : 0};
     return run(h, 1, a, stream, "mpe_episodes");
 }

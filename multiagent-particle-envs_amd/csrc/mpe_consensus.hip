@@ -45,10 +45,10 @@ template <typename T> __device__ __forceinline__ T f32r(T v) { return (T)(float)
 
 // MODE 0: mpe_step, 1: mpe_rollout / mpe_episode, 2: mpe_observe
 template <typename T, int MODE>
-__global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> p, const ResetArgs rs, const int* __restrict__ actions,
+__global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> p, const ResetArgs rs, const AutoArgs au, const int* __restrict__ actions,
                                                        T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ hist_g,
                                                        int* __restrict__ aux_g, T* __restrict__ obs_g, T* __restrict__ rew_g,
-                                                       uint8_t* __restrict__ done_g, int n_steps) {
+                                                       uint8_t* __restrict__ done_g, T* __restrict__ obs0_g, int n_steps) {
     __shared__ T tile_obs[64 * CSTRIDE];
     __shared__ T tile_rew[64 * CA];
     const int lane = threadIdx.x;
@@ -63,11 +63,11 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
 
     V2<T> pos[CA], vel[CA];
     int head;
-    if (MODE == 1 && rs.enabled) {
-        // reset_world, consensus.py:46-59: agents U(-1,1)^2 at rest, every history row equal to the start
+    // reset_world, consensus.py:46-59: agents U(-1,1)^2 at rest, every history row equal to the start
+    auto reset_world = [&](const ResetArgs& r) {
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
-            const V2<double> d = reset_draw(rs, (unsigned long long)b, i, true);
+            const V2<double> d = reset_draw(r, (unsigned long long)b, i, true);
             pos[i].x = (T)d.x; pos[i].y = (T)d.y;
             vel[i].x = T(0); vel[i].y = T(0);
         }
@@ -80,6 +80,9 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
                     hist_g[hrow(s, i, 2)] = T(0); hist_g[hrow(s, i, 3)] = T(0);
                 }
         }
+    };
+    if (MODE == 1 && rs.enabled) {
+        reset_world(rs);
     } else {
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
@@ -90,9 +93,24 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
         head = (head < 0 || head >= CH) ? 0 : head;
     }
 
-    for (int t = 0; t < n_steps; ++t) {
+    // Episode launches with obs0: the observation of every freshly reset state (what MultiAgentEnv.reset returns,
+    // environment.py:122-127) is produced by a pass through the loop body that skips the step and the rewards
+    // ("pre") before the episode's first step, so the observation code exists once.
+    const bool want_obs0 = (MODE == 1) && rs.enabled && obs0_g != nullptr;
+    bool pre = want_obs0;
+    int t = 0, last_reset = 0;
+    while (t < n_steps) {
         const long long row = (long long)t * B + env0;
-        if (MODE != 2) {
+        if (MODE == 1 && rs.enabled && rs.period > 0 && t % rs.period == 0 && t != last_reset) {
+            // next episode of a launch of several (mpe_episodes)
+            ResetArgs nr = rs;
+            nr.episode = rs.episode + (unsigned long long)(t / rs.period);
+            reset_world(nr);
+            last_reset = t;
+            pre = want_obs0;
+        }
+        bool finished = false;
+        if (MODE != 2 && !pre) {
             // ---- _set_action (environment.py:176-195) and World.step (new_core.py:188-205) ----
 #pragma unroll
             for (int i = 0; i < CA; ++i) {
@@ -125,7 +143,8 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
         }
 
         // ---- reward(), consensus.py:91-113; shared by np.sum over the six agents (environment.py:103-105) ----
-        if (MODE != 2 || rew_g != nullptr) {
+        const bool want_score = !pre && (MODE != 2 || rew_g != nullptr);
+        if (want_score) {
             T own[CA];
 #pragma unroll
             for (int i = 0; i < CA; ++i) {
@@ -143,6 +162,26 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
             for (int i = 1; i < CA; ++i) total = total + own[i];
 #pragma unroll
             for (int i = 0; i < CA; ++i) tile_rew[lane * CA + i] = (MODE == 2) ? own[i] : total;   // observe: what the callback returns
+            if (MODE == 0 && au.step_count != nullptr) {
+                // ---- episode bookkeeping (mpe_step_auto): returns, step counter, time-limit reset ----
+                T* ep = (T*)au.ep_return + b * CA;
+                const int cnt = au.step_count[b] + 1;
+                finished = cnt >= au.max_steps;
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < CA; ++i) {
+                        const T sum = ep[i] + total;
+                        ep[i] = finished ? T(0) : sum;
+                        if (finished) ((T*)au.last_return)[b * CA + i] = sum;
+                    }
+                    au.step_count[b] = finished ? 0 : cnt;
+                }
+                if (finished) {       // Scenario.reset_world with the next episode's draws; obs below is the fresh one
+                    const int epi = au.episode_count[b] + 1;
+                    if (valid) au.episode_count[b] = epi;
+                    reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0});
+                }
+            }
         }
 
         // ---- observation(), consensus.py:122-140, one agent at a time ----
@@ -150,6 +189,8 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
         // loads one more agent's 40 values and drops one (agent 5's stay for the end, agent 0's are
         // fetched again for agent 5), 7 agent histories per world-step instead of 18.
         {
+            T* const block = pre ? obs0_g + ((long long)(rs.period > 0 ? t / rs.period : 0) * B + env0) * (CA * COBS)
+                                 : obs_g + row * (CA * COBS);      // the wave's 64 rows of the env-major array
             T H[CA][4 * CH];
             auto load_agent = [&](int j) {
 #pragma unroll
@@ -183,7 +224,7 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
                 // of the row for both float types): vector g covers values [VEC * g, VEC * g + VEC) of row g / NVR
                 constexpr int VEC = 16 / (int)sizeof(T), NVR = COBS / VEC;
                 typedef T VT __attribute__((ext_vector_type(VEC)));
-                T* gbase = obs_g + row * (CA * COBS) + i * COBS;
+                T* gbase = block + i * COBS;
 #pragma unroll 4
                 for (int it = 0; it < NVR; ++it) {          // 64 * NVR vectors, 64 per iteration
                     const int g = it * 64 + lane;
@@ -196,15 +237,18 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
                 __syncthreads();
             }
         }
-        if (MODE != 2 || rew_g != nullptr) {
+        if (want_score) {
             const int n = nvalid * CA;
             for (int it = 0; it < CA; ++it) {
                 const int g = it * 64 + lane;
                 if (g < n) rew_g[row * CA + g] = tile_rew[g];
             }
-            if (MODE != 2 && valid) done_g[row + lane] = 0;      // no done callback (environment.py:143-146)
+            // no done callback (environment.py:143-146); mpe_step_auto flags the step that reaches its time limit
+            if (MODE != 2 && valid) done_g[row + lane] = finished ? 1 : 0;
             __syncthreads();
         }
+        if (pre) pre = false;
+        else ++t;
     }
 
     if (MODE != 2 && valid) {
@@ -256,11 +300,11 @@ hipError_t launch_consensus_t(const HostSpec& s, long long B, int mode, const St
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     T *pos = (T*)a.pos, *vel = (T*)a.vel, *hist = (T*)a.comm, *obs = (T*)a.obs, *rew = (T*)a.rew;
     if (mode == 0)
-        hipLaunchKernelGGL((consensus_kernel<T, 0>), grid, block, 0, st, p, a.reset, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, 1);
+        hipLaunchKernelGGL((consensus_kernel<T, 0>), grid, block, 0, st, p, a.reset, a.au, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);
     else if (mode == 1)
-        hipLaunchKernelGGL((consensus_kernel<T, 1>), grid, block, 0, st, p, a.reset, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, a.n_steps);
+        hipLaunchKernelGGL((consensus_kernel<T, 1>), grid, block, 0, st, p, a.reset, a.au, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)a.obs0, a.n_steps);
     else
-        hipLaunchKernelGGL((consensus_kernel<T, 2>), grid, block, 0, st, p, a.reset, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, 1);
+        hipLaunchKernelGGL((consensus_kernel<T, 2>), grid, block, 0, st, p, a.reset, a.au, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);
     return hipGetLastError();
 }
 

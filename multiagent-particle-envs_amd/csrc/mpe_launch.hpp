@@ -78,6 +78,7 @@ struct StepArgs {
     ResetArgs reset;
     AutoArgs au;
     int32_t* aux;             // [n_aux][B] per-episode scenario state (landmark indices), or NULL
+    void* obs0;               // episode launches: T[n_episodes][B][obs_total] observation of each reset state, or NULL
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112

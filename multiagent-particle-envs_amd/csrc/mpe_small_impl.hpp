@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                                                    T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                    T* __restrict__ obs_g, T* __restrict__ rew_g,
                                                    uint8_t* __restrict__ done_g, int* __restrict__ info_i_g,
-                                                   T* __restrict__ info_f_g, int* __restrict__ aux_g, int n_steps) {
+                                                   T* __restrict__ info_f_g, int* __restrict__ aux_g, T* __restrict__ obs0_g, int n_steps) {
     constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
     constexpr int NI = Cfg::NI > 0 ? Cfg::NI : 1, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C, NX = Cfg::N_AUX;
     constexpr int NC = Cfg::S * Cfg::DIM_C;      // comm state values: the speakers' utterances in agent order
@@ -290,12 +290,20 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 
     int to_reset = (MODE == MODE_ROLLOUT && rs.enabled && rs.period > 0) ? rs.period : 0x7fffffff;     // steps until the next episode starts
     unsigned long long episode = rs.episode;
+    // obs0_g (episode launches, optional): the observation of every freshly reset state, what
+    // MultiAgentEnv.reset returns (environment.py:122-127).  It is produced by a pass through the step body
+    // that skips the physics, the rewards and post_step ("pre"), before the episode's first step.
+    const bool want_obs0 = (MODE == MODE_ROLLOUT) && rs.enabled && obs0_g != nullptr;
+    bool fresh = want_obs0;
+    long long ep_idx = 0;           // episodes started so far in this launch, minus one
     for (int t0 = 0; t0 < n_steps;) {
       if (MODE != MODE_OBSERVE) {
           if (t0 > 0) load_actions(t0);
           if (MODE == MODE_ROLLOUT && to_reset == 0) {
               // next episode of a multi-episode launch: Scenario.reset_world again, while the action words arrive
               episode += 1;
+              ep_idx += 1;
+              fresh = want_obs0;
               to_reset = rs.period;
               ResetArgs nr = rs;
               nr.episode = episode;
@@ -326,15 +334,16 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
       to_reset = (to_reset == 0x7fffffff) ? to_reset : to_reset - nc;
       if (t0 == 0) STAMP(1);
       unsigned __int128 packed = 0;
-      for (int kc = 0; kc < nc; ++kc) {
+      for (int kc = fresh ? -1 : 0; kc < nc; ++kc) {
+        const bool pre = (MODE == MODE_ROLLOUT) && kc < 0;      // the reset state's observation only
         const int t = t0 + kc;
-        if (kc % CH == 0) {          // next shift register (uniform select, NP is small)
+        if (!pre && kc % CH == 0) {          // next shift register (uniform select, NP is small)
             const int q = kc / CH;
             packed = fetched[0];
 #pragma unroll
             for (int j = 1; j < NP; ++j) if (q == j) packed = fetched[j];
         }
-        if (MODE != MODE_OBSERVE) {
+        if (MODE != MODE_OBSERVE && !pre) {
             const unsigned long long cur = (unsigned long long)packed;
             packed >>= ABITS;
             int act[NA];
@@ -407,12 +416,12 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
         }
 
         // ---- scenario callbacks into the wave's LDS tiles ----
-        const bool want_score = (MODE != MODE_OBSERVE) || (rew_g != nullptr);   // observe: rewards on request
+        const bool want_score = !pre && ((MODE != MODE_OBSERVE) || (rew_g != nullptr));   // observe: rewards on request
         bool finished = false;
         if (EPW == 64 || lane < EPW) {
             if (want_score)
                 Cfg::template score<T>(pos, comm, aux, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
-            if (Cfg::SHARED && MODE != MODE_OBSERVE) {
+            if (Cfg::SHARED && MODE != MODE_OBSERVE && !pre) {
                 // collaborative world: step hands every agent np.sum(reward_n) (environment.py:103-105);
                 // numpy adds fewer than 8 values left to right
                 static_assert(!Cfg::SHARED || A < 8, "np.sum switches to pairwise blocks at 8 values");
@@ -468,6 +477,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
         }
         const long long row0 = (long long)t * B + env0;
+        T* const obs_dst = pre ? obs0_g + (ep_idx * B + env0) * OT : obs_g + row0 * OT;
         if constexpr (Cfg::OBS_LOOP) {
             // one copy of the per-agent observation code, looped over the agents; every lane reads back only
             // the column of the staging area it wrote itself, so no barrier is needed before the first read
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 typedef T Pair __attribute__((ext_vector_type(2)));
                 static_assert(!Cfg::OBS_LOOP || (OT % 2 == 0 && S % 2 == 0 && Cfg::CHUNK_MIN % 2 == 0 && Cfg::CHUNK_MAX % 2 == 0), "pairs need even widths");
                 static_assert(!Cfg::OBS_LOOP || (Cfg::CHUNK_MIN / 2 > 32 && Cfg::CHUNK_MAX / 2 < 64), "a 64-pair stride crosses one or two row ends");
-                Pair* gbase = reinterpret_cast<Pair*>(obs_g + row0 * OT + Cfg::chunk_offset(i));
+                Pair* gbase = reinterpret_cast<Pair*>(obs_dst + Cfg::chunk_offset(i));
                 const Pair* tile2 = reinterpret_cast<const Pair*>(tile_obs);
                 const int W2 = W / 2, n = nvalid * W2;
                 int r = 0, j = lane;
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 __syncthreads();
                 int nv = nvalid - pass * TROWS;
                 nv = nv < 0 ? 0 : (nv > TROWS ? TROWS : nv);
-                ObsTile::template flush<FULL>(tile_obs, obs_g + (row0 + pass * TROWS) * OT, lane, nv);
+                ObsTile::template flush<FULL>(tile_obs, obs_dst + (long long)(pass * TROWS) * OT, lane, nv);
                 __syncthreads();
             }
         } else if constexpr (Cfg::OBS_CHUNKS > 1)
@@ -524,14 +534,14 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             // per-step work and frees those registers.
             int lane_s = lane;
             asm volatile("" : "+v"(lane_s));
-            ObsChunks<T, Cfg, 0, EPW, FULL>::run(pos, vel, comm, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_g + row0 * OT, lane_s,
+            ObsChunks<T, Cfg, 0, EPW, FULL>::run(pos, vel, comm, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_dst, lane_s,
                                                  tile_lane, EPW == 64 || lane < EPW, nvalid);
         }
         // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
         // reset starts its episode untouched
-        if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, (unsigned long long)b);
+        if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, (unsigned long long)b);
         __syncthreads();
-        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0) ObsTile::template flush<FULL>(tile_obs, obs_g + row0 * OT, lane, nvalid);
+        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0) ObsTile::template flush<FULL>(tile_obs, obs_dst, lane, nvalid);
         if (want_score) {
             RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane, nvalid);
             if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
@@ -556,10 +566,11 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             }
         }
         if (MODE == MODE_ROLLOUT) {
-            if (t < 28) STAMP(2 + t);
+            if (t >= 0 && t < 28) STAMP(2 + t);
             __syncthreads();   // tiles are rewritten by the next step
         }
       }
+      fresh = false;
       t0 += nc;
     }
 
@@ -647,7 +658,7 @@ static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_
     if (env_end <= env_begin) return;
     const dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
     hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
-                       (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.aux, a.n_steps);
+                       (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.aux, (T*)a.obs0, a.n_steps);
 }
 
 // Full tiles run the straight-line FULL instantiation; the ragged tail (and every wave when the

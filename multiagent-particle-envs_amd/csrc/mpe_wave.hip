@@ -42,7 +42,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                                                   const T* __restrict__ u_g, const T* __restrict__ c_g,
                                                   T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                   T* __restrict__ obs_g, T* __restrict__ rew_g, uint8_t* __restrict__ done_g,
-                                                  int* __restrict__ info_i_g, T* __restrict__ info_f_g, int n_steps) {
+                                                  int* __restrict__ info_i_g, T* __restrict__ info_f_g, T* __restrict__ obs0_g, int n_steps) {
     // entity positions (agents first) and agent velocities in one array, so that the observation
     // loop can fetch either with one computed index
     __shared__ V2<T> PV[MAX_E + MPE_MAX_AGENTS];
@@ -61,25 +61,34 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     const long long B = p.n_envs;
     const DevTable* tb = p.table;
 
-    // ---- stage the world ----
-    for (int e = lane; e < E; e += NT) {
-        if (rs.enabled) {       // fused Scenario.reset_world (same draws as reset_kernel)
-            const V2<double> d = reset_draw(rs, (unsigned long long)b, e, e < A);
+    // Scenario.reset_world into LDS (same draws as reset_kernel): positions, zero velocities; the landmarks,
+    // which the step loop never writes back, go to pos_g at once.  Ends with the workgroup in step.
+    auto draw_world = [&](const ResetArgs& r) {
+        for (int e = lane; e < E; e += NT) {
+            const V2<double> d = reset_draw(r, (unsigned long long)b, e, e < A);
             P[e].x = (T)d.x;
             P[e].y = (T)d.y;
-            if (e >= A) {       // landmarks are not written back by the step loop
+            if (e >= A) {
                 pos_g[b * (2 * E) + 2 * e] = P[e].x;
                 pos_g[b * (2 * E) + 2 * e + 1] = P[e].y;
             }
-        } else {
+        }
+        if (lane < A) { Vel[lane].x = T(0); Vel[lane].y = T(0); }
+        __syncthreads();
+    };
+    // ---- stage the world ----
+    for (int e = lane; e < E; e += NT) size_s[e] = (T)tb->size[e];
+    if (rs.enabled) {       // fused Scenario.reset_world
+        draw_world(rs);
+    } else {
+        for (int e = lane; e < E; e += NT) {
             P[e].x = pos_g[b * (2 * E) + 2 * e];
             P[e].y = pos_g[b * (2 * E) + 2 * e + 1];
         }
-        size_s[e] = (T)tb->size[e];
-    }
-    if (lane < A) {
-        Vel[lane].x = rs.enabled ? T(0) : vel_g[b * (2 * A) + 2 * lane];
-        Vel[lane].y = rs.enabled ? T(0) : vel_g[b * (2 * A) + 2 * lane + 1];
+        if (lane < A) {
+            Vel[lane].x = vel_g[b * (2 * A) + 2 * lane];
+            Vel[lane].y = vel_g[b * (2 * A) + 2 * lane + 1];
+        }
     }
     if (lane == 0) {
         int n = 0;
@@ -115,8 +124,58 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     const bool want_info = (info_i_g != nullptr);
     const int OD = 4 + 2 * L + 2 * (A - 1);      // simple_spread observation length
 
+    // the packed copy of the colliding entities follows P (after a reset)
+    auto repack = [&]() {
+        for (int k = lane; k < n_coll; k += NT) {
+            const int j = coll_idx[k];
+            CP[k][0] = P[j].x; CP[k][1] = P[j].y;
+        }
+        __syncthreads();
+    };
+    // ---- observation(), simple_spread.py:110-130: rows of RP = OD/2 coordinate pairs ----
+    // Pair r of agent i's row is Vel[i] (r = 0), P[i] (r = 1) or P[src] - P[i]; the loop is branch-
+    // free (one computed index into PV, the subtrahend masked out for r < 2) so that the LDS
+    // reads of several iterations are in flight together, and (i, r) advance incrementally.
+    auto emit_obs = [&](T* world_block) {
+        const int RP = OD / 2, total = A * RP;
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        // the world's block starts at a multiple of A*OD values and OD is even: pair q is 2*sizeof(T)-aligned
+        T2* dst = reinterpret_cast<T2*>(world_block) + lane;
+        int i = (int)(((float)lane + 0.5f) / (float)RP), r = lane - i * RP;      // lane < 128: exact
+        #pragma unroll 4
+        for (int q = lane; q < total; q += NT, dst += NT) {
+            const int m = r - 2 - L;
+            const int src = (m < 0) ? A + r - 2 : m + (m >= i ? 1 : 0);
+            const int first = (r == 0) ? MAX_E + i : (r == 1 ? i : src);
+            const V2<T> sa = PV[first], sb = PV[i];
+            const bool rel = r >= 2;
+            T2 w;
+            w.x = spread_round<T>(sa.x - (rel ? sb.x : T(0)));
+            w.y = spread_round<T>(sa.y - (rel ? sb.y : T(0)));
+            *dst = w;
+            r += NT;
+            while (r >= RP) { r -= RP; ++i; }       // once when RP >= 128; worlds with a short row have few pairs
+        }
+    };
+
     for (int t = 0; t < n_steps; ++t) {
         const long long row = (long long)t * B + b;
+        if (EPI == EPI_SPREAD && MODE == WMODE_STEP && rs.enabled) {
+            // episode launches: a launch of several episodes resets again every rs.period steps; the
+            // observation of every freshly reset state goes to obs0 (what MultiAgentEnv.reset returns)
+            const bool again = rs.period > 0 && t > 0 && t % rs.period == 0;
+            if (again) {
+                __syncthreads();
+                ResetArgs nr = rs;
+                nr.episode = rs.episode + (unsigned long long)(t / rs.period);
+                draw_world(nr);
+                repack();
+            }
+            if ((t == 0 || again) && obs0_g != nullptr) {
+                const long long ep = rs.period > 0 ? t / rs.period : 0;
+                emit_obs(obs0_g + (ep * B + b) * (long long)(A * OD));
+            }
+        }
         if (MODE != WMODE_OBSERVE) {
             V2<T> pi = P[me], vi = Vel[me];
             if (is_agent && i_move) {   // a wave without agents goes straight to the barrier
@@ -274,47 +333,11 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                 }
                 if (finished) {     // Scenario.reset_world with the next episode's draws
                     const ResetArgs nr{1, au.seed, (unsigned long long)epi, au.landmark_lim};
-                    for (int e = lane; e < E; e += NT) {
-                        const V2<double> d = reset_draw(nr, (unsigned long long)b, e, e < A);
-                        P[e].x = (T)d.x;
-                        P[e].y = (T)d.y;
-                        if (e >= A) {
-                            pos_g[b * (2 * E) + 2 * e] = P[e].x;
-                            pos_g[b * (2 * E) + 2 * e + 1] = P[e].y;
-                        }
-                    }
-                    if (is_agent) { Vel[lane].x = T(0); Vel[lane].y = T(0); }
-                    __syncthreads();
-                    for (int k = lane; k < n_coll; k += NT) {       // keep the packed copy in step
-                        const int j = coll_idx[k];
-                        CP[k][0] = P[j].x; CP[k][1] = P[j].y;
-                    }
-                    __syncthreads();
+                    draw_world(nr);
+                    repack();
                 }
             }
-            // ---- observation(), simple_spread.py:110-130: rows of RP = OD/2 coordinate pairs ----
-            // Pair r of agent i's row is Vel[i] (r = 0), P[i] (r = 1) or P[src] - P[i]; the loop is branch-
-            // free (one computed index into PV, the subtrahend masked out for r < 2) so that the LDS
-            // reads of several iterations are in flight together, and (i, r) advance incrementally.
-            const int RP = OD / 2, total = A * RP;
-            typedef T T2 __attribute__((ext_vector_type(2)));
-            // the world's block starts at a multiple of A*OD values and OD is even: pair q is 2*sizeof(T)-aligned
-            T2* dst = reinterpret_cast<T2*>(obs_g + row * (long long)(A * OD)) + lane;
-            int i = (int)(((float)lane + 0.5f) / (float)RP), r = lane - i * RP;      // lane < 128: exact
-            #pragma unroll 4
-            for (int q = lane; q < total; q += NT, dst += NT) {
-                const int m = r - 2 - L;
-                const int src = (m < 0) ? A + r - 2 : m + (m >= i ? 1 : 0);
-                const int first = (r == 0) ? MAX_E + i : (r == 1 ? i : src);
-                const V2<T> sa = PV[first], sb = PV[i];
-                const bool rel = r >= 2;
-                T2 w;
-                w.x = spread_round<T>(sa.x - (rel ? sb.x : T(0)));
-                w.y = spread_round<T>(sa.y - (rel ? sb.y : T(0)));
-                *dst = w;
-                r += NT;
-                while (r >= RP) { r -= RP; ++i; }       // once when RP >= 128; worlds with a short row have few pairs
-            }
+            emit_obs(obs_g + row * (long long)(A * OD));
         }
     }
 
@@ -341,10 +364,10 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
     const dim3 grid((unsigned)B), block(NT);
     if (s.any_speed_limit())
         hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, true>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
-                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
+                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.n_steps);
     else
         hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
-                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.n_steps);
+                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.n_steps);
     return hipGetLastError();
 }
 
@@ -363,7 +386,8 @@ hipError_t launch_wave(const HostSpec& s, const DevTable* table, long long B, in
 hipError_t launch_world_step(const HostSpec& s, const DevTable* table, long long B, int dtype, const void* u, const void* c, void* pos,
                              void* vel, void* comm, int n_speak_rows, hipStream_t st) {
     if (B > 0x7fffffffLL) return hipErrorInvalidValue;
-    const StepArgs a{nullptr, pos, vel, comm, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    StepArgs a{};
+    a.pos = pos; a.vel = vel; a.comm = comm; a.n_steps = 1;
     return dtype == MPE_F64 ? launch_wave_t<double, EPI_NONE, WMODE_STEP>(s, table, B, a, u, c, n_speak_rows, st)
                             : launch_wave_t<float, EPI_NONE, WMODE_STEP>(s, table, B, a, u, c, n_speak_rows, st);
 }

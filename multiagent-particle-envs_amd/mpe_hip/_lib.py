@@ -65,9 +65,10 @@ EXPORTS = {
     # (..., info_f, step_count, episode_count, ep_return, last_return, max_steps, seed, stream)
     "mpe_step_auto": (C.c_int, [C.c_void_p] + [C.c_void_p] * 14 + [C.c_int32, C.c_uint64, C.c_void_p]),
     "mpe_rollout": (C.c_int, [C.c_void_p] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
-    "mpe_episode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
-    # (handle, seed, first_episode, n_episodes, steps_per_episode, actions, pos, vel, comm, aux, obs, rew, done, info_i, info_f, stream)
-    "mpe_episodes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32] + [C.c_void_p] * 10 + [C.c_void_p]),
+    # (handle, seed, episode, actions, pos, vel, comm, aux, obs, rew, done, info_i, info_f, obs0, n_steps, stream)
+    "mpe_episode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 11 + [C.c_int32, C.c_void_p]),
+    # (handle, seed, first_episode, n_episodes, steps_per_episode, actions, pos, vel, comm, aux, obs, rew, done, info_i, info_f, obs0, stream)
+    "mpe_episodes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + [C.c_void_p]),
     # (handle, pos, vel, comm, aux, obs, rew, info_i, info_f, stream)
     "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]),
     "mpe_post_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -161,20 +161,26 @@ class BatchedEnv:
                                                    p["info_i"], p["info_f"], self._stream()))
         return self.obs, self.rew, self.done, (self.info_i, self.info_f)
 
-    def rollout(self, actions, out=None, reset_seed=None, episodes=1):
+    def rollout(self, actions, out=None, reset_seed=None, episodes=1, obs0=False):
         """``T`` steps in one launch for pre-computed actions ``[T, B, n_act]``.  Returns a dict of
         ``[T, ...]`` tensors (pass the previous result as ``out`` to reuse its buffers).  With
         ``reset_seed`` every env is first reset on device inside the same launch (one episode per
         launch, like ``reset(seed, observe=False)`` followed by ``rollout``); with ``episodes`` = K > 1
-        the T steps are K consecutive episodes of T / K steps, each starting with its own reset."""
+        the T steps are K consecutive episodes of T / K steps, each starting with its own reset.  With
+        ``obs0`` the launch also returns the observation of every reset state, ``out["obs0"]``
+        ``[K, B, obs_total]`` (what ``reset()`` returns)."""
         T = int(actions.shape[0])
         a = self._actions(actions, (T,))
         lo, B = self.layout, self.n_envs
-        if out is None or out["obs"].shape[0] != T:
+        if obs0 and reset_seed is None:
+            raise ValueError("obs0 is the observation of an on-device reset: pass reset_seed")
+        if out is None or out["obs"].shape[0] != T or (obs0 and (out.get("obs0") is None or out["obs0"].shape[0] != episodes)):
             z = lambda *shape, dt=self.dtype: torch.empty(*shape, dtype=dt, device=self.device)
             out = {"obs": z(T, B, lo.obs_total), "rew": z(T, B, self.n_agents), "done": z(T, B, dt=torch.uint8),
                    "info_i": z(T, B, lo.n_info_i, dt=torch.int32) if self.info_i is not None else None,
-                   "info_f": z(T, B, lo.n_info_f) if self.info_f is not None else None}
+                   "info_f": z(T, B, lo.n_info_f) if self.info_f is not None else None,
+                   "obs0": z(int(episodes), B, lo.obs_total) if obs0 else None}
+        first = _ptr(out.get("obs0")) if obs0 else None
         p = self._p
         if reset_seed is None:
             _lib.check(self._h, self._lib.mpe_rollout(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["aux"], _ptr(out["obs"]),
@@ -185,12 +191,12 @@ class BatchedEnv:
                 raise ValueError("%d steps do not split into %d episodes" % (T, episodes))
             _lib.check(self._h, self._lib.mpe_episodes(self._h, int(reset_seed), self._episode, int(episodes), T // episodes, _ptr(a), p["pos"],
                                                        p["vel"], p["comm"], p["aux"], _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]),
-                                                       _ptr(out["info_i"]), _ptr(out["info_f"]), self._stream()))
+                                                       _ptr(out["info_i"]), _ptr(out["info_f"]), first, self._stream()))
             self._episode += int(episodes)
         else:
             _lib.check(self._h, self._lib.mpe_episode(self._h, int(reset_seed), self._episode, _ptr(a), p["pos"], p["vel"], p["comm"],
                                                       p["aux"], _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]),
-                                                      _ptr(out["info_f"]), T, self._stream()))
+                                                      _ptr(out["info_f"]), first, T, self._stream()))
             self._episode += 1
         return out
 

@@ -48,6 +48,8 @@ def test_algorithmic_bytes_match_the_survey_figures():
     # simple_spread 3/3 float32: 313 B per env-step as single steps; an episode launch reads no state
     assert bench.algorithmic_bytes(3, 3, 3, 42, 4, 1) == 313
     assert abs(bench.algorithmic_bytes(3, 3, 3, 42, 4, 25, reads_state=False) - 194.92) < 1e-9
+    # ... and with the reset state's observation written once per episode: + 168 / 25
+    assert abs(bench.algorithmic_bytes(3, 3, 3, 42, 4, 25, reads_state=False, reset_obs=True) - 201.64) < 1e-9
     assert bench.algorithmic_bytes(4, 2, 4, 62, 4, 1) == 425                 # simple_tag
     assert bench.algorithmic_bytes(64, 64, 64, 64 * 258, 4, 1) == 69121     # simple_spread 64/64
 

@@ -27,9 +27,6 @@ def test_layout_and_refusals():
     env = _env(8, torch.float64)
     assert env.obs_dims == list(g["obs_dims"]) and env.n_act == 6 and env.layout.n_hist_rows == 240 and env.layout.n_aux == 1
     assert tuple(env.comm.shape) == (240, 8)
-    with pytest.raises(mpe_hip.MpeError):
-        e = _env(8, torch.float32, max_episode_steps=5)
-        e.step(torch.zeros(8, 6, dtype=torch.int32))
     with pytest.raises(ValueError):
         _env(8, torch.float32, info=True)
 
@@ -73,6 +70,35 @@ def test_rollout_and_episode_equal_stepping(dtype):
         assert torch.equal(out2[k], out3[k]), k
     for k in ("pos", "vel", "comm", "aux"):
         assert torch.equal(getattr(e1, k), getattr(e2, k)) and torch.equal(getattr(e1, k), getattr(e3, k)), k
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_step_auto_truncates_resets_and_keeps_returns(dtype):
+    """mpe_step_auto against plain mpe_step with the bookkeeping done here: running and finished returns, the
+    done flag on the step that reaches the limit, and a reset (history ring included) equal to mpe_reset's."""
+    dt = getattr(torch, dtype)
+    B, H = 130, 7
+    auto, ref = _env(B, dt, max_episode_steps=H, seed=21), _env(B, dt)
+    assert torch.equal(auto.reset(seed=21), ref.reset(seed=21))
+    gen = torch.Generator("cuda:0").manual_seed(3)
+    ret = torch.zeros(B, 6, dtype=dt, device="cuda:0")
+    for t in range(2 * H + 3):
+        a = torch.randint(0, 5, (B, 6), dtype=torch.int32, device="cuda:0", generator=gen)
+        oa, ra, da, _ = auto.step(a)
+        orr, rr, _, _ = ref.step(a)
+        assert torch.equal(ra, rr), t
+        ret += rr
+        if (t + 1) % H == 0:
+            assert da.all() and torch.equal(auto.last_return, ret) and not auto.ep_return.any() and not auto.step_count.any()
+            ret.zero_()
+            assert torch.equal(oa, ref.reset(seed=21)), t           # the next episode's draws, observed
+            assert (auto.episode_count == (t + 1) // H).all()
+        else:
+            assert not da.any() and torch.equal(oa, orr) and torch.equal(auto.ep_return, ret), t
+        for k in ("pos", "vel", "comm"):
+            assert torch.equal(getattr(auto, k), getattr(ref, k)), (t, k)
+        # ring heads differ after a reset (0 against wherever the stepping left it) only in position, not in content
+        assert torch.equal(torch.as_tensor(auto.get_history()[0]), torch.as_tensor(ref.get_history()[0]))
 
 
 def test_large_batch_fp64_against_oracle_with_masked_reset():

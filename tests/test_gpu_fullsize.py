@@ -118,7 +118,9 @@ def test_reset_is_reproducible_and_independent_of_batch_size():
 
 @pytest.mark.parametrize("scenario,dtype", [("simple_spread", "float32"), ("simple_spread", "float64"), ("simple_tag", "float32"),
                                             ("simple_world_comm", "float32"), ("simple_reference", "float64"),
-                                            ("simple_predator_prey", "float32"), ("collector", "float64")])
+                                            ("simple_predator_prey", "float32"), ("collector", "float64"),
+                                            ("consensus", "float32"), ("consensus", "float64"),
+                                            ("spread5", "float32"), ("spread5", "float64")])
 def test_multi_episode_launch_equals_single_episode_launches(scenario, dtype):
     """mpe_episodes(K) == K mpe_episode launches with consecutive episode numbers, bit for bit; B is not a
     multiple of the wave size for half of the cases."""
@@ -126,29 +128,30 @@ def test_multi_episode_launch_equals_single_episode_launches(scenario, dtype):
     dt = getattr(torch, dtype)
     B = 4096 if dtype == "float32" else 1000
     K, T = 3, 25
-    e1 = mpe_hip.BatchedEnv(scenario, B, dtype=dt, device="cuda:0", info=True)
-    e2 = mpe_hip.BatchedEnv(scenario, B, dtype=dt, device="cuda:0", info=True)
+    kw = dict(info=True)
+    if scenario == "spread5":                   # a wave-per-world size of simple_spread
+        scenario, kw, B = "simple_spread", dict(info=True, n_agents=5, n_landmarks=5), B // 8
+    if scenario == "consensus":                 # no benchmark outputs
+        kw = {}
+    e1 = mpe_hip.BatchedEnv(scenario, B, dtype=dt, device="cuda:0", **kw)
+    e2 = mpe_hip.BatchedEnv(scenario, B, dtype=dt, device="cuda:0", **kw)
     gen = torch.Generator("cuda:0").manual_seed(7)
     a = torch.stack([torch.randint(0, n, (K * T, B), dtype=torch.int32, device="cuda:0", generator=gen) for n in e1.action_dims], dim=2).contiguous()
     e1._episode = e2._episode = 5
-    out = e1.rollout(a, reset_seed=13, episodes=K)
-    assert e1._episode == 5 + K
+    out = e1.rollout(a, reset_seed=13, episodes=K, obs0=True)
+    assert e1._episode == 5 + K and out["obs0"].shape[0] == K
     for k in range(K):
-        o = e2.rollout(a[k * T:(k + 1) * T].contiguous(), reset_seed=13)
+        o = e2.rollout(a[k * T:(k + 1) * T].contiguous(), reset_seed=13, obs0=True)
         for key in ("obs", "rew", "done", "info_i", "info_f"):
             if o[key] is not None:
                 assert torch.equal(out[key][k * T:(k + 1) * T], o[key]), (scenario, k, key)
+        assert torch.equal(out["obs0"][k], o["obs0"][0]), (scenario, k)
+        # the reset observation is what mpe_reset + mpe_observe give for that episode
+        e3 = mpe_hip.BatchedEnv(scenario, B, dtype=dt, device="cuda:0", **kw)
+        e3._episode = 5 + k
+        assert torch.equal(e3.reset(seed=13), o["obs0"][0]), (scenario, k)
     assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.vel, e2.vel)
     if e1.aux is not None:
         assert torch.equal(e1.aux, e2.aux)
     if e1.comm is not None:
         assert torch.equal(e1.comm, e2.comm)
-
-
-def test_multi_episode_launch_is_refused_where_unsupported():
-    import mpe_hip
-    for scenario, kw in (("consensus", {}), ("simple_spread", dict(n_agents=5, n_landmarks=5))):
-        env = mpe_hip.BatchedEnv(scenario, 128, device="cuda:0", **kw)
-        a = torch.zeros(50, 128, env.n_act, dtype=torch.int32, device="cuda:0")
-        with pytest.raises(mpe_hip.MpeError):
-            env.rollout(a, reset_seed=1, episodes=2)

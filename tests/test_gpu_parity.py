@@ -321,9 +321,10 @@ def test_episode_equals_reset_then_rollout(case):
     a = torch.as_tensor(np.resize(g["actions"], (7, B, g["actions"].shape[2]))).to("cuda:0")
     for dt in (torch.float32, torch.float64):
         e1, e2 = _env(case, B, dt), _env(case, B, dt)
-        e1.reset(seed=9, observe=False)
+        first = e1.reset(seed=9).clone()                   # mpe_reset + mpe_observe: what MultiAgentEnv.reset returns
         o1 = e1.rollout(a)
-        o2 = e2.rollout(a, reset_seed=9)
+        o2 = e2.rollout(a, reset_seed=9, obs0=True)
+        assert o2["obs0"].shape == (1, B, e2.layout.obs_total) and torch.equal(o2["obs0"][0], first)
         assert torch.equal(o1["obs"], o2["obs"]) and torch.equal(o1["rew"], o2["rew"])
         assert torch.equal(o1["info_i"], o2["info_i"])
         assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.vel, e2.vel)
