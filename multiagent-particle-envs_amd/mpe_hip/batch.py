@@ -80,6 +80,7 @@ class BatchedEnv:
         self.info_i = z(B, lo.n_info_i, dt=torch.int32) if info else None
         self.info_f = z(B, lo.n_info_f) if (info and lo.n_info_f > 0) else None
         self._episode = 0
+        self._auto_since_reset = False
         # episode bookkeeping on device (mpe_step_auto): time-limit truncation + auto-reset + returns
         self.max_episode_steps = max_episode_steps
         self.seed = int(seed)
@@ -120,6 +121,10 @@ class BatchedEnv:
         the fresh observations like MultiAgentEnv.reset unless ``observe`` is False."""
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        if self.max_episode_steps is not None and self._auto_since_reset:
+            # automatic resets on the device have drawn episodes up to max(episode_count) of the seed: start
+            # beyond them, so that no env replays a world it (or a neighbour) has already played
+            self._episode = max(self._episode, int(self.episode_count.max().item()) + 1)
         p = self._p
         _lib.check(self._h, self._lib.mpe_reset(self._h, int(seed), self._episode, _ptr(mask), p["pos"], p["vel"], p["comm"],
                                                 p["aux"], self._stream()))
@@ -133,6 +138,7 @@ class BatchedEnv:
                     t.fill_(v)
                 else:
                     t[~keep] = v
+            self._auto_since_reset = True
         self._episode += 1
         return self.observe() if observe else None
 
@@ -254,6 +260,66 @@ class BatchedEnv:
         order = (head[:, None] + np.arange(10)[None, :]) % 10
         h = ring[np.arange(B)[:, None], order].transpose(0, 2, 1, 3)
         return h[..., :2].copy(), h[..., 2:].copy()
+
+    def to_world(self, b, world=None):
+        """Env ``b`` of the batch as a ``World`` object graph (entities with size / mass / flags and the current
+        ``state.p_pos`` / ``p_vel`` / ``c``), for code written against the reference's objects: a viewer
+        (multiagent/environment.py:214-328 reads ``entity.state.p_pos``, ``size``, ``color``), a ``Scenario``'s Python
+        callbacks, a debugger.  Pass the world of an earlier call to refresh it in place instead of building a new one.
+        The copy is a snapshot: stepping the batch does not move it, and stepping it does not touch the batch."""
+        from . import world as core, new_core
+        sp, A, L = self.spec, self.n_agents, self.n_landmarks
+        if not 0 <= b < self.n_envs:
+            raise IndexError("env %d out of range for a batch of %d" % (b, self.n_envs))
+        if world is None:
+            mod = new_core if sp.new_core else core
+            world = mod.World()
+            world.dim_c = sp.dim_c
+            world.dt, world.damping, world.contact_force, world.contact_margin = sp.dt, sp.damping, sp.contact_force, sp.contact_margin
+            world.collaborative = bool(sp.collaborative)
+            world.device = str(self.device)
+            for i in range(A):
+                a = mod.Agent()
+                a.name, a.i = "agent %d" % i, i
+                a.movable, a.collide, a.silent = bool(sp.movable[i]), bool(sp.collide[i]), bool(sp.silent[i])
+                a.size, a.initial_mass = float(sp.size[i]), float(sp.mass[i])
+                acc = sp.accel[i] if sp.accel is not None else sp.sensitivity[i]
+                a.accel = None if (np.isnan(acc) or (sp.accel is None and acc == 5.0)) else float(acc)
+                a.max_speed = None if np.isinf(sp.max_speed[i]) else float(sp.max_speed[i])
+                a.adversary, a.leader = bool(sp.adversary[i]), bool(sp.leader[i])
+                a.ghost = bool(sp.ghost[i]) if sp.ghost is not None else False
+                a.color = np.array([0.85, 0.35, 0.35]) if a.adversary else np.array([0.35, 0.35, 0.85])
+                a.action.u, a.action.c = np.zeros(2), np.zeros(sp.dim_c)
+                world.agents.append(a)
+            for l in range(L):
+                lm = mod.Landmark()
+                lm.name, lm.i = "landmark %d" % l, A + l
+                lm.movable, lm.collide = False, bool(sp.collide[A + l])
+                lm.size, lm.initial_mass = float(sp.size[A + l]), float(sp.mass[A + l])
+                lm.color = np.array([0.25, 0.25, 0.25])
+                world.landmarks.append(lm)
+            world.walls = [core.Wall(orient=w["orient"], axis_pos=w["axis_pos"], endpoints=tuple(w["endpoints"]), width=w["width"], hard=w["hard"])
+                           for w in sp.walls]
+        elif len(world.agents) != A or len(world.landmarks) != L:
+            raise ValueError("the world passed in does not have this batch's entities")
+        one = (lambda t: t[b]) if self.env_major else (lambda t: t[:, b])
+        pos = one(self.pos).cpu().numpy().astype(np.float64).reshape(A + L, 2)
+        vel = one(self.vel).cpu().numpy().astype(np.float64).reshape(A, 2)
+        n_c = self.layout.n_speakers * self.layout.dim_c
+        comm = one(self.comm)[:n_c].cpu().numpy().astype(np.float64) if (self.comm is not None and n_c > 0) else None
+        for e, p in zip(world.entities, pos):
+            e.state.p_pos = p.copy()
+            e.state.p_vel = np.zeros(2)
+        world.unpack_state(pos[None], vel[None], None if comm is None else comm[None])
+        if self.layout.n_hist_rows > 0:         # consensus: the sliding history, oldest first
+            ring = self.comm[:, b].reshape(10, A, 4).cpu().numpy().astype(np.float64)
+            head = int(self.aux[0, b])
+            order = (head + np.arange(10)) % 10
+            for i, a in enumerate(world.agents):
+                a.state.p_his_pos, a.state.p_his_vel = ring[order, i, :2].copy(), ring[order, i, 2:].copy()
+        if getattr(world, "cache_dists", False):
+            world.calculate_distances()
+        return world
 
     @property
     def goal(self):

@@ -21,6 +21,20 @@ from . import spaces
 from .scenario import HipScenario
 
 
+def _accepts_two_positionals(fn):
+    """Whether ``fn(world, np_random)`` is a valid call (bound methods: self is already taken)."""
+    if fn is None:
+        return False
+    import inspect
+    try:
+        params = list(inspect.signature(fn).parameters.values())
+    except (TypeError, ValueError):
+        return True                     # no signature to inspect (a builtin): call it as the reference does
+    if any(p.kind == p.VAR_POSITIONAL for p in params):
+        return True
+    return len([p for p in params if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]) >= 2
+
+
 class MultiAgentEnv:
     metadata = {"render.modes": ["human", "rgb_array"]}
 
@@ -41,6 +55,10 @@ class MultiAgentEnv:
         self.shared_reward = bool(getattr(world, "collaborative", False))
         self.shared_viewer = shared_viewer
         self.np_random = None
+        # the reference always calls reset_callback(world, np_random) (environment.py:119); scenarios whose
+        # reset_world takes only the world (simple_tag.py:39) are called without the generator.  Decided once
+        # from the signature, so that an error inside the callback is never mistaken for a wrong arity.
+        self._reset_takes_rng = _accepts_two_positionals(reset_callback)
         # a built-in scenario drives the fused kernel when it owns every callback that was passed
         owner = getattr(reward_callback, "__self__", None)
         cbs = [cb for cb in (reset_callback, reward_callback, observation_callback, info_callback) if cb is not None]
@@ -78,9 +96,9 @@ class MultiAgentEnv:
         (simple_tag.py:39) are called without the generator."""
         if self.np_random is None:
             raise AttributeError("call env.seed(seed) before env.reset() (the reference has no np_random until seeded)")
-        try:
+        if self._reset_takes_rng:
             self.reset_callback(self.world, self.np_random)
-        except TypeError:
+        else:
             self.reset_callback(self.world)
         self.agents = self.world.policy_agents
         return [self._get_obs(a) for a in self.agents]

@@ -185,3 +185,48 @@ def test_world_with_walls_steps_on_gpu():
         w.step()
         assert _close([a.state.p_pos for a in w.agents], g["pos"][t, b]), t
         assert _close([a.state.p_vel for a in w.agents], g["vel"][t, b]), t
+
+
+@pytest.mark.parametrize("scenario", ["simple_tag", "simple_world_comm", "simple_predator_prey", "consensus"])
+def test_batch_slice_as_world_objects(scenario):
+    """BatchedEnv.to_world(b): one env of a batch as the reference's object graph.  The scenario's own callbacks on
+    that world give the batch's observation row, and stepping the copy is stepping that env."""
+    import mpe_hip
+    from mpe_hip.scenarios import load
+    B, b = 37, 23
+    env = mpe_hip.BatchedEnv(scenario, B, dtype=torch.float64)
+    obs = env.reset(seed=4).clone()
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for _ in range(12):          # move away from the reset state (consensus: fills its history)
+        a = torch.stack([torch.randint(0, n, (B,), dtype=torch.int32, device="cuda", generator=gen) for n in env.action_dims], dim=1).contiguous()
+        obs = env.step(a)[0].clone()
+    world = env.to_world(b)
+    sc = load(scenario + ".py").Scenario()
+    mine = sc.make_world()
+    assert [e.size for e in world.entities] == [e.size for e in mine.entities]
+    assert [(a.max_speed, a.accel, a.silent, a.collide) for a in world.agents] == [(a.max_speed, a.accel, a.silent, a.collide) for a in mine.agents]
+    assert len(world.walls) == len(mine.walls)
+    pos, vel, _ = env.get_state()
+    assert np.array_equal(np.array([e.state.p_pos for e in world.entities]), pos[b])
+    assert np.array_equal(np.array([a.state.p_vel for a in world.agents]), vel[b])
+    if scenario == "simple_predator_prey":       # the scenario's helper lists and int state live beside the entities
+        world.barrier, world.foods, world.forests = world.landmarks[:1], world.landmarks[1:4], world.landmarks[4:]
+        flags = int(env.aux[0, b])
+        for k, f in enumerate(world.foods):
+            f.alive = bool(flags >> k & 1)
+        for k, m in enumerate(world.agents[4:]):
+            m.holding = bool(flags >> (3 + k) & 1)
+    if scenario == "consensus":
+        world.comm_matrix = mine.comm_matrix
+    got = np.concatenate([sc.observation(a, world) for a in world.agents])
+    now = env.observe()         # the callbacks on the current state (a post_step may have changed it since the step's own)
+    assert np.array_equal(got, now[b].cpu().numpy().astype(got.dtype))
+    if scenario != "simple_predator_prey":
+        assert torch.equal(now, obs)
+    # refreshing an existing world in place
+    a = torch.zeros(B, env.n_act, dtype=torch.int32, device="cuda")
+    env.step(a)
+    again = env.to_world(b, world)
+    assert again is world and np.array_equal(np.array([e.state.p_pos for e in world.entities]), env.get_state()[0][b])
+    with pytest.raises(IndexError):
+        env.to_world(B)

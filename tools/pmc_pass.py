@@ -17,11 +17,11 @@ scn, envs, names = sys.argv[1], sys.argv[2], sys.argv[3:]
 out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%d" % (scn, os.getpid()))
 os.environ["TMPDIR"] = "/tmp"
 cmd = ["rocprofv3", "--pmc"] + names + ["--output-format", "csv", "-d", out, "--", "python3", "bench.py", "--no-cpu-baseline", "--no-step-mode",
-                                        "--scenario", scn, "--envs", envs, "--steps", "250", "--warmup", "25"]
+                                        "--scenario", scn, "--envs", envs, "--steps", "250", "--warmup", "25", "--target-steps", "250"]
 rc = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200).returncode
 if rc != 0:
     sys.exit("rocprofv3 failed with %d" % rc)
-mode_re = re.compile(r"(?:>|Cfg), (?:true|false), 1, (?:true|false), (?:true|false), \d+>\(|consensus_kernel<\w+, 1>")
+mode_re = re.compile(r"(?:>|Cfg), (?:true|false), 1, (?:true|false), (?:true|false), \d+>\(|consensus_kernel<\w+, 1>|wave_kernel<\w+, 1, 0")
 acc = {n: [] for n in names}
 for fn in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(fn)):

@@ -5,7 +5,7 @@ run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline "$@"
 import json,sys
 n=sys.argv[1]; d=json.load(open('gpurun_out/configs/%s.json'%n))
 r=d['roofline']; s=d.get('step_mode') or {}
-print('%-22s %7.2f G agent-steps/s  %.3f us/step | kernel %.4f ms  %.0f GB/s frac %.3f | step-mode %.2f G/s %.2f us frac %.3f' % (n, d['value']/1e9, d['ms_per_step']*1e3, r['launch_ms_hip_events'], r['achieved'], r['frac'], s.get('value',0)/1e9, s.get('launch_ms_hip_events',0)*1e3, s.get('roofline_frac',0)))
+print('%-22s %7.2f G agent-steps/s  %.3f us/step | kernel %.4f ms  %.0f GB/s frac %.3f | step-mode %.2f G/s %.2f us frac %.3f' % (n, d['value']/1e9, d['ms_per_step']*1e3, r['launch_ms'], r['achieved'], r['frac'], s.get('value',0)/1e9, s.get('launch_ms_hip_events',0)*1e3, s.get('roofline_frac',0)))
 PY
 }
 run spread3_B65536
