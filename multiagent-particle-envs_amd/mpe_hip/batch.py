@@ -64,31 +64,46 @@ class BatchedEnv:
             self.action_dims += ([5] if self.spec.movable[i] else []) + ([lo.dim_c] if not self.spec.silent[i] else [])
         self.obs_dims = [lo.obs_dim[i] for i in range(A)]
         self.obs_offsets = [lo.obs_offset[i] for i in range(A)]
-        z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
+        # Every persistent buffer is a view into ONE zero-initialised device allocation (the arena), each on
+        # a 256-byte boundary: inputs first (state, aux and -- for a one-world batch, whose caller stages
+        # host data -- the action / force / comm-action slots), then the outputs.  A one-world caller can
+        # then move all inputs with one copy and all results with another (mpe_hip/oneworld.py).
         self.env_major = bool(lo.state_env_major)
-        st = (lambda rows: z(B, rows)) if self.env_major else (lambda rows: z(rows, B))
-        self.pos = st(2 * (A + L))
-        self.vel = st(2 * A)
+        st = (lambda rows: (B, rows)) if self.env_major else (lambda rows: (rows, B))
         comm_rows = lo.n_speakers * lo.dim_c + lo.n_hist_rows       # consensus keeps its history ring in the comm buffer
-        self.comm = st(comm_rows) if comm_rows > 0 else None
-        self.aux = z(lo.n_aux, B, dt=torch.int32) if lo.n_aux > 0 else None
-        self.obs = z(B, lo.obs_total)
-        self.rew = z(B, A)
-        self.done = z(B, dt=torch.uint8)
         if info and lo.n_info_i == 0:
             raise ValueError("this scenario has no benchmark_data: info is not available")
-        self.info_i = z(B, lo.n_info_i, dt=torch.int32) if info else None
-        self.info_f = z(B, lo.n_info_f) if (info and lo.n_info_f > 0) else None
-        self._episode = 0
-        self._auto_since_reset = False
-        # episode bookkeeping on device (mpe_step_auto): time-limit truncation + auto-reset + returns
         self.max_episode_steps = max_episode_steps
         self.seed = int(seed)
+        self._episode = 0
+        self._auto_since_reset = False
+        i32, u8 = torch.int32, torch.uint8
+        fields = [("pos", st(2 * (A + L)), dtype), ("vel", st(2 * A), dtype)]
+        fields += [("comm", st(comm_rows), dtype)] if comm_rows > 0 else []
+        fields += [("aux", (lo.n_aux, B), i32)] if lo.n_aux > 0 else []
+        if B == 1:
+            fields += [("act_buf", (1, max(1, lo.n_act)), i32), ("u_buf", (1, 2 * A), dtype)]
+            fields += [("c_buf", (1, lo.n_speakers * lo.dim_c), dtype)] if lo.n_speakers > 0 else []
+        self._n_input_fields = len(fields)
+        fields += [("obs", (B, lo.obs_total), dtype), ("rew", (B, A), dtype), ("done", (B,), u8)]
+        if info:
+            fields += [("info_i", (B, lo.n_info_i), i32)]
+            fields += [("info_f", (B, lo.n_info_f), dtype)] if lo.n_info_f > 0 else []
         if max_episode_steps is not None:
-            self.step_count = z(B, dt=torch.int32)
-            self.episode_count = z(B, dt=torch.int32)
-            self.ep_return = z(B, A)
-            self.last_return = z(B, A)
+            # episode bookkeeping on device (mpe_step_auto): time-limit truncation + auto-reset + returns
+            fields += [("step_count", (B,), i32), ("episode_count", (B,), i32), ("ep_return", (B, A), dtype), ("last_return", (B, A), dtype)]
+        esize = {torch.float32: 4, torch.float64: 8, i32: 4, u8: 1}
+        self.arena_layout, off = {}, 0
+        for name, shape, dt in fields:
+            nbytes = int(np.prod(shape)) * esize[dt]
+            self.arena_layout[name] = (off, nbytes, tuple(shape), dt)
+            off = (off + nbytes + 255) // 256 * 256
+        self.arena = torch.zeros(max(off, 256), dtype=u8, device=self.device)
+        self.arena_input_bytes = max((o + n for k, (o, n, _, _) in list(self.arena_layout.items())[:self._n_input_fields]), default=0)
+        for name in ("comm", "aux", "info_i", "info_f"):
+            setattr(self, name, None)
+        for name, (o, n, shape, dt) in self.arena_layout.items():
+            setattr(self, name, self.arena[o:o + n].view(dt).view(*shape))
         # raw device pointers of the persistent buffers, resolved once (the tensors are never reallocated)
         self._p = {k: _ptr(getattr(self, k, None)) for k in ("pos", "vel", "comm", "aux", "obs", "rew", "done", "info_i", "info_f",
                                                              "step_count", "episode_count", "ep_return", "last_return")}

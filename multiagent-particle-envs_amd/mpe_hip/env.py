@@ -163,26 +163,30 @@ class MultiAgentEnv:
         assert not ints
 
     def _fused_step(self, action_n):
-        import torch
+        """One mpe_step launch on the one-world batch: the state goes up and every result comes down in one copy each."""
         sc, world = self._scenario, self.world
-        env = sc.fused_env(world)
+        ow = sc.one_world(world)
         flat = []
         for i, agent in enumerate(self.agents):
             flat += self._action_ints(action_n[i], agent)
-        sc.load_state(world, env)
-        env.step(torch.tensor([flat], dtype=torch.int32))
+        sc.stage(world, ow)
+        ow.step(flat)
         world.t += 1
-        world.unpack_state(*env.get_state())
+        pos, vel, comm = ow.state()
+        world.unpack_state(pos[None], vel[None], None if comm is None else comm[None])
         after = getattr(world, "after_step", None)      # new_core worlds: history and distance cache of the new state
         if after is not None:
             after()
-        sc.store(world, env)
-        obs_n = [sc.observation(a, world) for a in self.agents]
-        reward_n = [sc.reward(a, world) for a in self.agents]
-        info_list = [sc.benchmark_data(a, world) if self.info_callback is not None else {} for a in self.agents]
+        _, obs, rew, _, _ = sc.store(None, ow)
+        obs_n = sc.split_obs(obs, world)
+        reward_n = [float(r) for r in rew]
+        info_list = [{}] * self.n
+        if self.info_callback is not None:
+            with sc.pinned():           # benchmark_data formats the step's own outputs, no second look at the world
+                info_list = [sc.benchmark_data(a, world) for a in self.agents]
         if sc.dynamic:
             # the kernel ran post_step after the callbacks: take over its pick-ups, hand-overs and respawns
-            sc._absorb_from(world, env, self.np_random)
+            sc.absorb_from(world, ow, self.np_random)
         return obs_n, reward_n, info_list
 
     def _get_obs(self, agent):

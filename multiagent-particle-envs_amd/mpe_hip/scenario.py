@@ -52,61 +52,94 @@ class HipScenario(BaseScenario):
     dynamic = False          # the scenario has a post_step (the kernel applies it: int state in aux, landmarks move)
 
     def __init__(self):
-        self._env = None        # (signature, BatchedEnv)
+        self._ow = None         # (signature, OneWorld)
         self._cache = None      # (state key, obs [obs_total], rew [A], info_i, info_f)
+        self._pinned = False
 
     # -- device plumbing ------------------------------------------------
-    def fused_env(self, world):
-        from . import BatchedEnv
-        import torch
+    def one_world(self, world):
+        """The one-world batch (with its pinned host mirror) matching the world's static properties."""
+        from .oneworld import OneWorld
         sig = world._signature() + (tuple(bool(getattr(a, "adversary", False)) for a in world.agents),
                                     bool(getattr(world, "collaborative", False)))
-        if self._env is None or self._env[0] != sig:
+        if self._ow is None or self._ow[0] != sig:
             spec = spec_from_world(world, self.scenario_id, self.hip_name)
             want_info = self.has_info if self.fused_info is None else self.fused_info
-            self._env = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=world.device, info=want_info))
+            self._ow = (sig, OneWorld(spec, device=world.device, info=want_info))
             self._cache = None
-        return self._env[1]
+        return self._ow[1]
+
+    def fused_env(self, world):
+        """The BatchedEnv behind one_world(world) (sizes, layout)."""
+        return self.one_world(world).env
 
     def goal_index(self, world):
-        """Landmark indices reset_world drew for the episode: an int (the goal landmark the agents
-        share, ``agent.goal_a``), a list of ints, or None."""
+        """The scenario's aux rows for this world -- landmark indices reset_world drew for the episode (the goal
+        landmark the agents share, ``agent.goal_a``), or the int state a dynamic scenario keeps: an int, a list
+        of ints, or None."""
         g = getattr(world.agents[0], "goal_a", None)
         return None if g is None else world.landmarks.index(g)
+
+    def state_rows(self, world):
+        """(pos, vel, comm, aux) as the kernel's buffers hold them for this world."""
+        pos, vel, comm = world.pack_state()
+        return pos, vel, comm, self.goal_index(world)
 
     @staticmethod
     def _key(pos, vel, comm, goal):
         return pos.tobytes() + vel.tobytes() + (comm.tobytes() if comm is not None else b"") + \
             (b"-" if goal is None else np.asarray(goal, np.int64).tobytes())
 
-    @staticmethod
-    def _outputs(env):
-        """(obs, rew, info_i, info_f) of the one world; rew holds what the reward callback returns, so in
-        a collaborative world the agents' own rewards (info_f) rather than the shared sum a step leaves in rew."""
-        np_ = lambda t: None if t is None else t[0].cpu().numpy()
-        rew = np_(env.info_f)[:env.n_agents] if env.spec.collaborative else env.rew[0].cpu().numpy()
-        return env.obs[0].cpu().numpy(), rew, np_(env.info_i), np_(env.info_f)
+    def _outputs(self, ow):
+        """(obs, rew, info_i, info_f) of the one world, copied out of the host mirror; rew holds what the reward
+        callback returns, so in a collaborative world the agents' own rewards (info_f) rather than the shared sum a
+        step leaves in rew."""
+        v, env = ow.v, ow.env
+        info_i = v["info_i"][0].copy() if "info_i" in v else None
+        info_f = v["info_f"][0].copy() if "info_f" in v else None
+        rew = info_f[:env.n_agents] if (env.spec.collaborative and info_f is not None) else v["rew"][0].copy()
+        return v["obs"][0].copy(), rew, info_i, info_f
 
-    def load_state(self, world, env):
-        """Copy the world's state (and goal landmark) into the one-world batch."""
-        pos, vel, comm = world.pack_state()
-        goal = self.goal_index(world)
-        env.set_state(pos, vel, comm, goal=None if goal is None else [goal])
+    def stage(self, world, ow):
+        """Put the world's state into the host mirror; returns the cache key of that state."""
+        pos, vel, comm, goal = self.state_rows(world)
+        ow.put_state(pos, vel, comm, goal)
+        return self._key(pos, vel, comm, goal)
 
-    def store(self, world, env):
-        """Cache the callbacks' outputs that ``env`` holds for the world's current state."""
-        pos, vel, comm = world.pack_state()
-        self._cache = (self._key(pos, vel, comm, self.goal_index(world)),) + self._outputs(env)
+    def store(self, key, ow):
+        """Cache the callbacks' outputs ``ow`` holds for the state with this key."""
+        self._cache = (key,) + self._outputs(ow)
+        return self._cache
+
+    def pinned(self):
+        """Context in which evaluate() hands out the cached outputs as they are (those of the step just taken)
+        without comparing the world's state with the cache key."""
+        sc = self
+
+        class _Pin:
+            def __enter__(self):
+                sc._pinned = True
+
+            def __exit__(self, *exc):
+                sc._pinned = False
+        return _Pin()
 
     def evaluate(self, world):
-        pos, vel, comm = world.pack_state()
-        key = self._key(pos, vel, comm, self.goal_index(world))
+        if self._pinned:
+            return self._cache
+        pos, vel, comm, goal = self.state_rows(world)
+        key = self._key(pos, vel, comm, goal)
         if self._cache is None or self._cache[0] != key:
-            env = self.fused_env(world)
-            self.load_state(world, env)
-            env.observe(score=True)
-            self._cache = (key,) + self._outputs(env)
+            ow = self.one_world(world)
+            ow.put_state(pos, vel, comm, goal)
+            ow.observe(score=True)
+            self.store(key, ow)
         return self._cache
+
+    def split_obs(self, obs, world):
+        """The reference's obs_n list from the concatenated row."""
+        env = self.fused_env(world)
+        return [obs[o:o + d].astype(self.obs_dtype) for o, d in zip(env.obs_offsets, env.obs_dims)]
 
     # -- post_step on the device ------------------------------------------
     def absorb(self, world, aux, landmark_pos, np_random=None):
@@ -114,10 +147,10 @@ class HipScenario(BaseScenario):
         the world's objects.  Dynamic scenarios override it."""
         raise NotImplementedError()
 
-    def _absorb_from(self, world, env, np_random):
+    def absorb_from(self, world, ow, np_random):
         A = len(world.agents)
-        pos, _, _ = env.get_state()
-        self.absorb(world, [int(x) for x in env.aux[:, 0].cpu().numpy()], pos[0, A:], np_random)
+        pos, _, _ = ow.state()
+        self.absorb(world, [int(x) for x in ow.v["aux"].reshape(-1)], pos[A:].copy(), np_random)
         self._cache = None
 
     def post_step(self, world, np_random=None):
@@ -127,10 +160,10 @@ class HipScenario(BaseScenario):
         them from its argument); without one they come from the world's counter-based device stream."""
         if not self.dynamic:
             raise AttributeError("scenario %r defines no post_step" % self.hip_name)
-        env = self.fused_env(world)
-        self.load_state(world, env)
-        env.post_step()
-        self._absorb_from(world, env, np_random)
+        ow = self.one_world(world)
+        self.stage(world, ow)
+        ow.post_step()
+        self.absorb_from(world, ow, np_random)
 
     # -- the plugin callbacks --------------------------------------------
     def observation(self, agent, world):

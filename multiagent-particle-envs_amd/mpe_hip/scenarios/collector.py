@@ -116,10 +116,6 @@ class Scenario(HipScenario):
             w |= (int(t.type) & 1) << (12 + l) | int(bool(t.alive)) << (18 + l)
         return [w] + list(getattr(world, "respawn_stream", [0, 0]))
 
-    @staticmethod
-    def _key(pos, vel, comm, goal):
-        return pos.tobytes() + vel.tobytes() + np.asarray(goal, np.int64).tobytes()
-
     def benchmark_data(self, agent, world):
         """collector.py:132-155: (collected_treasures, deposited_treasures, collisions)."""
         i = world.agents.index(agent)

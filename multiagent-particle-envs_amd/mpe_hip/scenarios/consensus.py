@@ -20,7 +20,7 @@ class Scenario(HipScenario):
     obs_dtype = np.float32       # consensus.py:140
     has_info = True              # benchmark_data is defined (and constant: no landmarks, no collisions)
     fused_info = False
-    fused_step = False
+    fused_step = False       # a step's rew is the shared sum; the agents' own rewards come from mpe_observe
 
     def make_world(self):
         world = World()
@@ -64,39 +64,17 @@ class Scenario(HipScenario):
         """consensus.py:61-77 with no landmarks and non-colliding agents."""
         return (0, 0, 0, 0)
 
-    # -- device plumbing: the history travels in the comm buffer --------------------------------
+    # -- device plumbing: the history travels in the comm buffer as a ring whose oldest slot is aux row 0 ----
     def goal_index(self, world):
         return 0
 
-    @staticmethod
-    def _history(world):
-        hp = np.array([a.state.p_his_pos for a in world.agents], dtype=np.float64)[None]
-        hv = np.array([a.state.p_his_vel for a in world.agents], dtype=np.float64)[None]
-        return hp, hv
+    def state_rows(self, world):
+        pos, vel, _ = world.pack_state()
+        hp = np.array([a.state.p_his_pos for a in world.agents], dtype=np.float64)      # [A, 10, 2], oldest first
+        hv = np.array([a.state.p_his_vel for a in world.agents], dtype=np.float64)
+        ring = np.concatenate([hp, hv], axis=2).transpose(1, 0, 2).reshape(-1)          # rows (slot, agent, component)
+        return pos, vel, ring, 0
 
-    @staticmethod
-    def _outputs(env):
+    def _outputs(self, ow):
         # mpe_observe leaves what the reward callback returns (the agents' own rewards) in rew
-        return env.obs[0].cpu().numpy(), env.rew[0].cpu().numpy(), None, None
-
-    def load_state(self, world, env):
-        pos, vel, _ = world.pack_state()
-        env.set_state(pos, vel)
-        env.set_history(*self._history(world))
-
-    def _state_key(self, world):
-        pos, vel, _ = world.pack_state()
-        hp, hv = self._history(world)
-        return pos.tobytes() + vel.tobytes() + hp.tobytes() + hv.tobytes()
-
-    def store(self, world, env):
-        self._cache = (self._state_key(world),) + self._outputs(env)
-
-    def evaluate(self, world):
-        key = self._state_key(world)
-        if self._cache is None or self._cache[0] != key:
-            env = self.fused_env(world)
-            self.load_state(world, env)
-            env.observe(score=True)
-            self._cache = (key,) + self._outputs(env)
-        return self._cache
+        return ow.v["obs"][0].copy(), ow.v["rew"][0].copy(), None, None

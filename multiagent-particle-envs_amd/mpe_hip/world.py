@@ -128,10 +128,10 @@ class World:
                 tuple((a.max_speed, bool(a.silent), bool(getattr(a, "ghost", False)), a.accel if self.new_core else None) for a in self.agents),
                 tuple((w.orient, w.axis_pos, tuple(w.endpoints), w.width, bool(w.hard)) for w in self.walls), str(self.device))
 
-    def _physics_env(self):
-        """One-world physics handle matching the entities' current static properties."""
-        from . import BatchedEnv, physics_spec
-        import torch
+    def _physics_world(self):
+        """One-world physics handle (with its pinned host mirror) matching the entities' current static properties."""
+        from . import physics_spec
+        from .oneworld import OneWorld
         sig = self._signature()
         if self._phys is None or self._phys[0] != sig:
             A = len(self.agents)
@@ -147,7 +147,7 @@ class World:
                                 movable=[bool(e.movable) for e in ents], new_core=self.new_core,
                                 accel=[np.nan if a.accel is None else a.accel for a in self.agents],
                                 dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin)
-            self._phys = (sig, BatchedEnv(spec, 1, dtype=torch.float64, device=self.device))
+            self._phys = (sig, OneWorld(spec, device=self.device))
         return self._phys[1]
 
     def pack_state(self):
@@ -176,7 +176,7 @@ class World:
         self.t += 1
         for agent in self.scripted_agents:
             agent.action = agent.action_callback(agent, self)
-        env = self._physics_env()
+        ow = self._physics_world()
         A = len(self.agents)
         u = np.zeros((1, 2 * A))
         c_rows = []
@@ -192,6 +192,7 @@ class World:
                 cn = np.random.randn(*a.action.c.shape) * a.c_noise if a.c_noise else 0.0
                 c_rows.append(np.asarray(a.action.c, dtype=np.float64) + cn)
         pos, vel, comm = self.pack_state()
-        env.set_state(pos, vel, comm)
-        env.world_step(u, np.concatenate(c_rows)[None] if c_rows else None)
-        self.unpack_state(*env.get_state())
+        ow.put_state(pos, vel, comm)
+        ow.world_step(u, np.concatenate(c_rows) if c_rows else None)      # state up, one launch, state down
+        pos, vel, comm = ow.state()
+        self.unpack_state(pos[None], vel[None], None if comm is None else comm[None])
