@@ -147,6 +147,10 @@ typedef struct MpeSpec {
     int32_t reserved;
     const double* accel;           /* [A] Agent.accel, NaN when None; read when physics == MPE_PHYSICS_NEW_CORE
                                       (the action force is (mass * accel, or mass when None) * u, new_core.py:214) */
+    const double* u_noise;         /* [A] Agent.u_noise, 0 when None (NULL = none): standard deviation of the normal noise
+                                      added to the action force of a movable agent, core.py:165 / new_core.py:213-214 */
+    const double* c_noise;         /* [A] Agent.c_noise, 0 when None (NULL = none): the same for the comm state of a
+                                      speaking agent, core.py:211 */
 } MpeSpec;
 
 /* Derived sizes of the caller-allocated buffers. */
@@ -262,6 +266,22 @@ int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* ac
 int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_episodes, int32_t steps_per_episode,
                  const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done,
                  int32_t* info_i, void* info_f, void* obs0, mpe_stream_t stream);
+
+/*
+ * Where a world with Agent.u_noise / Agent.c_noise (MpeSpec.u_noise / c_noise; no built-in scenario sets them)
+ * takes its standard-normal draws, for which the reference calls np.random.randn (core.py:165,211):
+ *   draws == NULL  the device's counter-based generator keyed by (seed, env index, step number, agent); the step
+ *                  number counts the steps the handle has run since this call (every mpe_step / mpe_step_auto
+ *                  adds 1, a rollout or episode launch its n_steps), so a sequence of launches never reuses a draw
+ *   draws != NULL  for the NEXT stepping launch only: T[n_steps][B][stride] device array of the draws themselves,
+ *                  stride = 2A + S * dim_c rounded up to even; value 2i + d is the force noise of agent i
+ *                  (coordinate d), value 2A + j the j-th comm value of the speakers in agent order.  Lets a test feed
+ *                  the reference's own draws.  Later launches go back to the generator.
+ * Draws are scaled by the agent's noise level and added as the reference does; an agent whose level is 0 uses
+ * none.  A handle that never receives this call draws from seed 0.  mpe_world_step adds no noise: it takes
+ * the forces as given.  MPE_ERR_INVALID for a world without noise levels.
+ */
+int mpe_set_noise(MpeHandle* h, uint64_t seed, const void* draws);
 
 /*
  * Scenario.post_step alone (simple_predator_prey.py:83-107, collector.py:84-110), what MultiAgentEnv.step

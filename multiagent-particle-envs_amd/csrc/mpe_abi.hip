@@ -18,6 +18,9 @@ struct MpeHandle {
     int device;
     bool use_wave;          // wave-per-world kernels, env-major state
     DevTable* table;        // device copy of the per-entity table (wave kernels only)
+    // Agent.u_noise / c_noise draws: generator key, steps run since mpe_set_noise, and the draw array of the next launch
+    unsigned long long noise_seed, noise_step;
+    const void* noise_draws;
     char err[512];
 };
 
@@ -85,8 +88,8 @@ static const char* check_structure(const HostSpec& s) {
             for (int i = 0; i < A; ++i) {
                 if (s.collide[i] || !s.silent[i] || !s.movable[i]) return "consensus agents move, are silent and do not collide";
                 if (s.size[i] != s.size[0] || s.mass[i] != s.mass[0] || s.sens[i] != s.sens[0] || s.force_scale[i] != s.force_scale[0] ||
-                    s.ghost[i] != s.ghost[0] || isfinite(s.max_speed[i]))
-                    return "consensus agents share size, mass, accel and ghost and have no speed limit";
+                    s.ghost[i] != s.ghost[0] || isfinite(s.max_speed[i]) || s.u_noise[i] != s.u_noise[0])
+                    return "consensus agents share size, mass, accel, ghost and u_noise and have no speed limit";
             }
             return nullptr;
         case MPE_SCN_COLLECTOR:
@@ -260,6 +263,10 @@ static int read_spec(const MpeSpec* spec, int64_t n_envs, int dtype, int device,
         s.leader[i] = (spec->leader && spec->leader[i]) ? 1 : 0;
         s.ghost[i] = (spec->ghost && spec->ghost[i]) ? 1 : 0;
         if (isnan(s.max_speed[i])) return fail(nullptr, MPE_ERR_INVALID, "%s: max_speed[%d] is NaN (use +inf for no limit)", who, i);
+        s.u_noise[i] = spec->u_noise ? spec->u_noise[i] : 0.0;
+        s.c_noise[i] = spec->c_noise ? spec->c_noise[i] : 0.0;
+        if (!(s.u_noise[i] >= 0.0) || !(s.c_noise[i] >= 0.0) || isinf(s.u_noise[i]) || isinf(s.c_noise[i]))
+            return fail(nullptr, MPE_ERR_INVALID, "%s: u_noise / c_noise of agent %d must be finite and >= 0", who, i);
         s.force_scale[i] = 1.0;
         if (s.physics == MPE_PHYSICS_NEW_CORE) s.force_scale[i] = isnan(spec->accel[i]) ? s.mass[i] : s.mass[i] * spec->accel[i];
     }
@@ -289,7 +296,7 @@ static void fill_table(const HostSpec& s, DevTable& t) {
     memset(&t, 0, sizeof(t));
     const int A = s.A, L = s.L;
     for (int k = 0; k < A + L; ++k) { t.size[k] = s.size[k]; t.mass[k] = s.mass[k]; t.collide[k] = s.collide[k]; t.movable[k] = s.movable[k]; }
-    for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; t.ghost[i] = s.ghost[i]; t.force_scale[i] = s.force_scale[i]; }
+    for (int i = 0; i < A; ++i) { t.sens[i] = s.sens[i]; t.max_speed[i] = s.max_speed[i]; t.silent[i] = s.silent[i]; t.ghost[i] = s.ghost[i]; t.force_scale[i] = s.force_scale[i]; t.u_noise[i] = s.u_noise[i]; }
     t.n_walls = s.n_walls;
     t.new_core = s.physics == MPE_PHYSICS_NEW_CORE ? 1 : 0;
     for (int w = 0; w < s.n_walls; ++w) {
@@ -352,8 +359,13 @@ int mpe_layout(const MpeHandle* h, MpeLayout* out) {
 
 const char* mpe_last_error(const MpeHandle* h) { return h ? h->err : g_create_err; }
 
-static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, const char* who) {
+static int run(MpeHandle* h, int mode, const StepArgs& args, mpe_stream_t stream, const char* who) {
     if (!h) return MPE_ERR_INVALID;
+    StepArgs a = args;
+    if (mode != 2 && h->spec.any_noise()) {
+        a.noise = NoiseArgs{1, h->spec.noise_stride(), h->noise_draws, h->noise_seed, h->noise_step};
+        if (((uintptr_t)h->noise_draws & (h->dtype == MPE_F64 ? 7u : 3u)) != 0) return fail(h, MPE_ERR_INVALID, "%s: misaligned noise draws", who);
+    }
     if (h->spec.scenario == MPE_SCN_NONE) return fail(h, MPE_ERR_INVALID, "%s: handle was created with MPE_SCN_NONE; use mpe_world_step", who);
     if (!a.pos || !a.vel || !a.obs) return fail(h, MPE_ERR_INVALID, "%s: pos, vel and obs must not be NULL", who);
     if ((h->layout.n_speakers > 0 || h->layout.n_hist_rows > 0) && !a.comm)
@@ -381,6 +393,20 @@ static int run(MpeHandle* h, int mode, const StepArgs& a, mpe_stream_t stream, c
         : h->use_wave                           ? launch_wave(h->spec, h->table, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream)
                                                 : launch_small(h->spec, h->layout.n_envs, h->dtype, mode, a, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, who);
+    if (a.noise.enabled) {      // the launch used its draws: move on
+        h->noise_step += (unsigned long long)(mode == 1 ? a.n_steps : 1);
+        h->noise_draws = nullptr;
+    }
+    return MPE_OK;
+}
+
+int mpe_set_noise(MpeHandle* h, uint64_t seed, const void* draws) {
+    if (!h) return MPE_ERR_INVALID;
+    if (!h->spec.any_noise()) return fail(h, MPE_ERR_INVALID, "mpe_set_noise: no agent of this world has u_noise or c_noise");
+    if (h->spec.scenario == MPE_SCN_NONE) return fail(h, MPE_ERR_INVALID, "mpe_set_noise: mpe_world_step takes its forces as given and adds no noise");
+    h->noise_seed = seed;
+    h->noise_step = 0;
+    h->noise_draws = draws;
     return MPE_OK;
 }
 

@@ -29,7 +29,7 @@ constexpr int CSTRIDE = COBS + 1;
 
 template <typename T>
 struct ConsensusParams {
-    T size, mass, sens, force_scale;        // uniform over the agents (mpe_create checks)
+    T size, mass, sens, force_scale, u_noise;       // uniform over the agents (mpe_create checks)
     T dt, one_minus_damping, contact_force, contact_margin;
     T wall_axis_pos[CW], wall_end0[CW], wall_end1[CW], wall_width[CW];
     int wall_vertical[CW], wall_hard[CW];          // dwords: scalar loads cannot fetch single bytes of the kernel arguments
@@ -44,8 +44,9 @@ __host__ __device__ constexpr int nb_hi(int i) { return i == 0 ? CA - 1 : (i == 
 template <typename T> __device__ __forceinline__ T f32r(T v) { return (T)(float)v; }     // .astype(np.float32), consensus.py:140
 
 // MODE 0: mpe_step, 1: mpe_rollout / mpe_episode, 2: mpe_observe
-template <typename T, int MODE>
-__global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> p, const ResetArgs rs, const AutoArgs au, const int* __restrict__ actions,
+// NOISE: agents with u_noise (its own instantiation: the generator is an out-of-line call)
+template <typename T, int MODE, bool NOISE = false>
+__global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> p, const ResetArgs rs, const AutoArgs au, const NoiseArgs nz, const int* __restrict__ actions,
                                                        T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ hist_g,
                                                        int* __restrict__ aux_g, T* __restrict__ obs_g, T* __restrict__ rew_g,
                                                        uint8_t* __restrict__ done_g, T* __restrict__ obs0_g, int n_steps) {
@@ -117,6 +118,10 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
                 const int a = actions[((long long)t * B + b) * CA + i];
                 V2<T> f = decode_move<T>(a, p.sens);
                 f.x = p.force_scale * f.x; f.y = p.force_scale * f.y;           // new_core.py:214
+                if constexpr (NOISE) {                                          // + randn(2) * u_noise, new_core.py:213
+                    const V2<T> z = noise_pair<T>(nz, t, B, b, i);
+                    f.x = f.x + z.x * p.u_noise; f.y = f.y + z.y * p.u_noise;
+                }
                 // nothing collides (consensus.py:30); the walls act on every agent (:35-41, new_core.py:230-236)
 #pragma unroll
                 for (int w = 0; w < CW; ++w) {
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void consensus_reset_kernel(long long B, const
 template <typename T>
 ConsensusParams<T> make_consensus_params(const HostSpec& s, long long B) {
     ConsensusParams<T> p;
-    p.size = (T)s.size[0]; p.mass = (T)s.mass[0]; p.sens = (T)s.sens[0]; p.force_scale = (T)s.force_scale[0];
+    p.size = (T)s.size[0]; p.mass = (T)s.mass[0]; p.sens = (T)s.sens[0]; p.force_scale = (T)s.force_scale[0]; p.u_noise = (T)s.u_noise[0];
     p.dt = (T)s.dt; p.one_minus_damping = (T)(1 - s.damping); p.contact_force = (T)s.contact_force; p.contact_margin = (T)s.contact_margin;
     for (int w = 0; w < CW; ++w) {
         p.wall_axis_pos[w] = (T)s.wall_axis_pos[w]; p.wall_end0[w] = (T)s.wall_end0[w]; p.wall_end1[w] = (T)s.wall_end1[w];
@@ -299,12 +304,16 @@ hipError_t launch_consensus_t(const HostSpec& s, long long B, int mode, const St
     const auto p = make_consensus_params<T>(s, B);
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     T *pos = (T*)a.pos, *vel = (T*)a.vel, *hist = (T*)a.comm, *obs = (T*)a.obs, *rew = (T*)a.rew;
-    if (mode == 0)
-        hipLaunchKernelGGL((consensus_kernel<T, 0>), grid, block, 0, st, p, a.reset, a.au, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);
+    if (mode == 0 && a.noise.enabled)
+        hipLaunchKernelGGL((consensus_kernel<T, 0, true>), grid, block, 0, st, p, a.reset, a.au, a.noise, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);
+    else if (mode == 1 && a.noise.enabled)
+        hipLaunchKernelGGL((consensus_kernel<T, 1, true>), grid, block, 0, st, p, a.reset, a.au, a.noise, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)a.obs0, a.n_steps);
+    else if (mode == 0)
+        hipLaunchKernelGGL((consensus_kernel<T, 0>), grid, block, 0, st, p, a.reset, a.au, a.noise, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);
     else if (mode == 1)
-        hipLaunchKernelGGL((consensus_kernel<T, 1>), grid, block, 0, st, p, a.reset, a.au, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)a.obs0, a.n_steps);
+        hipLaunchKernelGGL((consensus_kernel<T, 1>), grid, block, 0, st, p, a.reset, a.au, a.noise, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)a.obs0, a.n_steps);
     else
-        hipLaunchKernelGGL((consensus_kernel<T, 2>), grid, block, 0, st, p, a.reset, a.au, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);
+        hipLaunchKernelGGL((consensus_kernel<T, 2>), grid, block, 0, st, p, a.reset, a.au, a.noise, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);
     return hipGetLastError();
 }
 

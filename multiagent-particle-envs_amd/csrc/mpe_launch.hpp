@@ -22,6 +22,16 @@ struct HostSpec {
     int n_walls;
     uint8_t wall_vertical[MPE_MAX_WALLS], wall_hard[MPE_MAX_WALLS];
     double wall_axis_pos[MPE_MAX_WALLS], wall_end0[MPE_MAX_WALLS], wall_end1[MPE_MAX_WALLS], wall_width[MPE_MAX_WALLS];
+    double u_noise[MPE_MAX_AGENTS], c_noise[MPE_MAX_AGENTS];     // Agent.u_noise / c_noise, 0 when None (core.py:165,211)
+    bool any_noise() const {
+        for (int i = 0; i < A; ++i) if (u_noise[i] != 0.0 || c_noise[i] != 0.0) return true;
+        return false;
+    }
+    int noise_stride() const {      // values per (step, env) row of a caller-supplied draw array
+        int n = 2 * A;
+        for (int i = 0; i < A; ++i) n += silent[i] ? 0 : dim_c;
+        return (n + 1) & ~1;
+    }
     int E() const { return A + L; }
     // rows of per-episode scenario state: the landmark indices reset_world draws
     int n_aux() const {
@@ -43,6 +53,7 @@ struct DevTable {
     double size[MAX_E], mass[MAX_E];
     double sens[MPE_MAX_AGENTS], max_speed[MPE_MAX_AGENTS], force_scale[MPE_MAX_AGENTS];
     double wall_axis_pos[MPE_MAX_WALLS], wall_end0[MPE_MAX_WALLS], wall_end1[MPE_MAX_WALLS], wall_width[MPE_MAX_WALLS];
+    double u_noise[MPE_MAX_AGENTS];     // Agent.u_noise, 0 when None
     uint8_t collide[MAX_E], movable[MAX_E], silent[MPE_MAX_AGENTS], ghost[MPE_MAX_AGENTS];
     uint8_t wall_vertical[MPE_MAX_WALLS], wall_hard[MPE_MAX_WALLS];
     int n_walls;
@@ -68,6 +79,14 @@ struct AutoArgs {
     double landmark_lim;
 };
 
+// Where the standard-normal draws of Agent.u_noise / Agent.c_noise come from (mpe_math.hpp: noise_pair).
+struct NoiseArgs {
+    int enabled;                        // the world has an agent with u_noise or c_noise
+    int stride;                         // values per (step, env) row of `draws`: 2A + S * dim_c, rounded up to even
+    const void* draws;                  // T[n_steps][B][stride]: [2i + d] force noise of agent i, [2A + j] comm value j; or NULL
+    unsigned long long seed, step0;     // generator key and the step number of the launch's first step
+};
+
 struct StepArgs {
     const int32_t* actions;
     void *pos, *vel, *comm, *obs, *rew;
@@ -79,6 +98,7 @@ struct StepArgs {
     AutoArgs au;
     int32_t* aux;             // [n_aux][B] per-episode scenario state (landmark indices), or NULL
     void* obs0;               // episode launches: T[n_episodes][B][obs_total] observation of each reset state, or NULL
+    NoiseArgs noise;          // enabled only for worlds with u_noise / c_noise
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mpe_launch.hpp"
+
 namespace mpe {
 
 template <typename T> struct V2 { T x, y; };
@@ -317,6 +319,41 @@ __device__ inline V2<double> respawn_draw(int key, unsigned long long b, int n, 
     d.x = -lim + (lim + lim) * Philox::u01(r.w0, r.w1);
     d.y = -lim + (lim + lim) * Philox::u01(r.w2, r.w3);
     return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Agent.u_noise / Agent.c_noise (multiagent/core.py:165,211): standard-normal draws scaled by the agent's
+// noise level, added to the action force and to the comm state.  The reference takes them from numpy's
+// global generator; here they come either from an array the caller supplies (the reference's own draws,
+// for parity) or from the counter-based generator: pair k of world b at step number n is Box-Muller on the
+// Philox block with key seed ^ "noise" and counter (b, n * 256 + k).
+// ---------------------------------------------------------------------------------------------
+
+// Out of line (one copy per kernel, results in registers): the float64 log / cos / sin are long.
+__device__ __noinline__ inline V2<double> normal_pair_call(unsigned long long seed, unsigned long long b, unsigned long long ctr) {
+    uint32_t r[4];
+    Philox::block(0x6E6F697365000000ull ^ seed, b, ctr, r);
+    const double u1 = 1.0 - Philox::u01(r[0], r[1]);        // (0, 1]
+    const double u2 = Philox::u01(r[2], r[3]);
+    const double rad = sqrt(-2.0 * log(u1));
+    V2<double> z;
+    z.x = rad * cos(2.0 * 3.141592653589793 * u2);
+    z.y = rad * sin(2.0 * 3.141592653589793 * u2);
+    return z;
+}
+
+// Pair k of world b at step t of the launch (values 2k and 2k + 1 of the row).
+template <typename T>
+__device__ __forceinline__ V2<T> noise_pair(const NoiseArgs& nz, long long t, long long B, long long b, int k) {
+    V2<T> z;
+    if (nz.draws != nullptr) {
+        const T* d = static_cast<const T*>(nz.draws) + ((t * B + b) * (long long)nz.stride + 2 * k);
+        z.x = d[0]; z.y = d[1];
+    } else {
+        const V2<double> n = normal_pair_call(nz.seed, (unsigned long long)b, (nz.step0 + (unsigned long long)t) * 256ull + (unsigned long long)k);
+        z.x = (T)n.x; z.y = (T)n.y;
+    }
+    return z;
 }
 
 }  // namespace mpe

@@ -25,6 +25,7 @@ struct SmallParams {
     T wall_axis_pos[SMALL_MAX_WALLS], wall_end0[SMALL_MAX_WALLS], wall_end1[SMALL_MAX_WALLS], wall_width[SMALL_MAX_WALLS];
     int wall_vertical[SMALL_MAX_WALLS], wall_hard[SMALL_MAX_WALLS], ghost[A];      // dwords: scalar loads cannot fetch single bytes of the kernel arguments
     double size_d[E];                           // float64 sizes for the reset's placement test
+    T u_noise[A], c_noise[A];                   // Agent.u_noise / c_noise, 0 when None; read when the launch's NoiseArgs is enabled
 };
 
 // Defaults of a scenario description; a scenario overrides what differs.  The constexpr helpers are force-inlined:

@@ -145,14 +145,17 @@ __device__ long long g_stamps[4096 * 64];
 // INFO: info_i / info_f are written.  env_begin / env_end: the env range this launch covers.
 // rs.enabled (rollout launches only): instead of loading the state, draw a fresh one exactly as
 //   reset_kernel would (Scenario.reset_world), so an episode is a single launch.
-template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW>
+// NOISE: the world has agents with u_noise / c_noise (its own instantiation: the generator is an out-of-line
+//   call, and a kernel with a call site pays for the calling convention in registers on every path).
+template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false>
 __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs, const AutoArgs au,
                                                    const long long env_begin, const long long env_end,
                                                    const int* __restrict__ actions, T* __restrict__ pos_g,
                                                    T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                    T* __restrict__ obs_g, T* __restrict__ rew_g,
                                                    uint8_t* __restrict__ done_g, int* __restrict__ info_i_g,
-                                                   T* __restrict__ info_f_g, int* __restrict__ aux_g, T* __restrict__ obs0_g, int n_steps) {
+                                                   T* __restrict__ info_f_g, int* __restrict__ aux_g, T* __restrict__ obs0_g, const NoiseArgs nz,
+                                                   int n_steps) {
     constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
     constexpr int NI = Cfg::NI > 0 ? Cfg::NI : 1, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C, NX = Cfg::N_AUX;
     constexpr int NC = Cfg::S * Cfg::DIM_C;      // comm state values: the speakers' utterances in agent order
@@ -365,6 +368,31 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 #pragma unroll
                     for (int c = 0; c < DC; ++c) comm[slot * DC + c] = (word == c) ? T(1) : T(0);   // update_agent_state
                     ++slot;
+                }
+            }
+            if constexpr (NOISE) {
+                // Agent.u_noise: p_force = action.u (scaled) + randn(2) * u_noise (core.py:165, new_core.py:213-214);
+                // Agent.c_noise: state.c = action.c + randn(dim_c) * c_noise (core.py:211).  An agent whose level is
+                // 0 (None in the reference) takes no draw.
+                int cslot = 0;
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    if (Cfg::movable(i) && p.u_noise[i] != T(0)) {
+                        const V2<T> z = noise_pair<T>(nz, t, B, b, i);
+                        force[i].x = force[i].x + z.x * p.u_noise[i];
+                        force[i].y = force[i].y + z.y * p.u_noise[i];
+                    }
+                    if (Cfg::speaks(i)) {
+                        if (p.c_noise[i] != T(0)) {
+#pragma unroll
+                            for (int c = 0; c < DC; ++c) {
+                                const int j = cslot * DC + c;           // value j of the row's comm part: pair A + j / 2
+                                const V2<T> z = noise_pair<T>(nz, t, B, b, A + j / 2);
+                                comm[j] = comm[j] + ((j & 1) ? z.y : z.x) * p.c_noise[i];
+                            }
+                        }
+                        ++cslot;
+                    }
                 }
             }
             // ---- World.apply_environment_force: pairs in the reference's (a, b) order ----
@@ -643,6 +671,7 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     p.contact_margin = (T)s.contact_margin;
     p.n_envs = n_envs;
     for (int e = 0; e < Cfg::E; ++e) p.size_d[e] = s.size[e];
+    for (int i = 0; i < Cfg::A; ++i) { p.u_noise[i] = (T)s.u_noise[i]; p.c_noise[i] = (T)s.c_noise[i]; }
     for (int i = 0; i < Cfg::A; ++i) { p.force_scale[i] = (T)s.force_scale[i]; p.ghost[i] = s.ghost[i]; }
     for (int w = 0; w < SMALL_MAX_WALLS; ++w) {
         const bool on = w < s.n_walls;
@@ -653,18 +682,24 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     return p;
 }
 
-template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW>
+template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false>
 static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_begin, long long env_end, const StepArgs& a, hipStream_t st) {
     if (env_end <= env_begin) return;
     const dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
-    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
-                       (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.aux, (T*)a.obs0, a.n_steps);
+    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW, NOISE>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
+                       (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.aux, (T*)a.obs0, a.noise, a.n_steps);
 }
 
 // Full tiles run the straight-line FULL instantiation; the ragged tail (and every wave when the
 // per-step output blocks are not 16-byte aligned, i.e. B % 4 != 0) runs the guarded 64-wide one.
 template <typename T, class Cfg, bool CLAMP, int MODE, bool INFO, int EPW>
 static void launch_epw(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, const StepArgs& a, hipStream_t st) {
+    if constexpr (MODE != MODE_OBSERVE) {
+        if (a.noise.enabled) {      // a rare configuration: every wave runs the guarded instantiation with the noise terms
+            launch_range<T, Cfg, CLAMP, MODE, false, INFO, (EPW < 64 ? EPW : 64), true>(p, 0, B, a, st);
+            return;
+        }
+    }
     const long long n_full = ((B & 3) == 0) ? (B / EPW) * EPW : 0;
     launch_range<T, Cfg, CLAMP, MODE, true, INFO, EPW>(p, 0, n_full, a, st);
     launch_range<T, Cfg, CLAMP, MODE, false, INFO, (EPW < 64 ? EPW : 64)>(p, n_full, B, a, st);

@@ -37,12 +37,14 @@ struct WaveParams {
 
 template <typename T> __device__ __forceinline__ T spread_round(T v) { return (T)(float)v; }
 
-template <typename T, int EPI, int MODE, bool CLAMP>
+// NOISE: agents with u_noise (its own instantiation: the generator is an out-of-line call).
+template <typename T, int EPI, int MODE, bool CLAMP, bool NOISE = false>
 __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const ResetArgs rs, const AutoArgs au, const int* __restrict__ actions,
                                                   const T* __restrict__ u_g, const T* __restrict__ c_g,
                                                   T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                   T* __restrict__ obs_g, T* __restrict__ rew_g, uint8_t* __restrict__ done_g,
-                                                  int* __restrict__ info_i_g, T* __restrict__ info_f_g, T* __restrict__ obs0_g, int n_steps) {
+                                                  int* __restrict__ info_i_g, T* __restrict__ info_f_g, T* __restrict__ obs0_g, const NoiseArgs nz,
+                                                  int n_steps) {
     // entity positions (agents first) and agent velocities in one array, so that the observation
     // loop can fetch either with one computed index
     __shared__ V2<T> PV[MAX_E + MPE_MAX_AGENTS];
@@ -184,6 +186,14 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                 if (EPI == EPI_SPREAD) {
                     const int a = is_agent ? actions[row * A + lane] : 0;
                     f = decode_move<T>(a, my_sens);                       // environment.py:176-195
+                    if constexpr (NOISE) {      // p_force = action.u + randn(2) * u_noise (core.py:165)
+                        const T un = (T)tb->u_noise[me];
+                        if (un != T(0)) {
+                            const V2<T> z = noise_pair<T>(nz, t, B, b, lane);
+                            f.x = f.x + z.x * un;
+                            f.y = f.y + z.y * un;
+                        }
+                    }
                 } else {
                     // agent.action.u as given; the scale is 1 (core.py:166) or mass (* accel) (new_core.py:214)
                     f.x = my_force_scale * u_g[b * (2 * A) + 2 * lane];
@@ -362,12 +372,23 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
     p.n_envs = B;
     p.A = s.A; p.L = s.L; p.dim_c = s.dim_c; p.n_speak_rows = n_speak_rows;
     const dim3 grid((unsigned)B), block(NT);
+    if constexpr (EPI == EPI_SPREAD && MODE == WMODE_STEP) {
+        if (a.noise.enabled) {
+            if (s.any_speed_limit())
+                hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, true, true>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c, (T*)a.pos,
+                                   (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.noise, a.n_steps);
+            else
+                hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false, true>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c, (T*)a.pos,
+                                   (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.noise, a.n_steps);
+            return hipGetLastError();
+        }
+    }
     if (s.any_speed_limit())
         hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, true>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
-                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.n_steps);
+                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.noise, a.n_steps);
     else
         hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c, (T*)a.pos, (T*)a.vel,
-                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.n_steps);
+                           (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.noise, a.n_steps);
     return hipGetLastError();
 }
 

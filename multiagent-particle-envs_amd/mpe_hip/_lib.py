@@ -35,6 +35,7 @@ class MpeSpec(C.Structure):
         ("wall_vertical", _p_u8), ("wall_axis_pos", _p_f64), ("wall_end0", _p_f64), ("wall_end1", _p_f64),
         ("wall_width", _p_f64), ("wall_hard", _p_u8), ("ghost", _p_u8),
         ("physics", C.c_int32), ("reserved", C.c_int32), ("accel", _p_f64),
+        ("u_noise", _p_f64), ("c_noise", _p_f64),
     ]
 
 
@@ -72,6 +73,8 @@ EXPORTS = {
     # (handle, pos, vel, comm, aux, obs, rew, info_i, info_f, stream)
     "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]),
     "mpe_post_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # (handle, seed, draws)
+    "mpe_set_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     # (handle, seed, episode, mask, pos, vel, comm, aux, stream)
     "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),

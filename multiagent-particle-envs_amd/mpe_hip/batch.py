@@ -221,6 +221,28 @@ class BatchedEnv:
             self._episode += 1
         return out
 
+    def set_noise(self, seed=0, noise_u=None, noise_c=None):
+        """Source of the standard-normal draws of ``Agent.u_noise`` / ``Agent.c_noise`` (multiagent/core.py:165,211) for a
+        spec that sets them.  Without arrays: the device generator keyed by ``seed``, restarted at step 0.  With
+        ``noise_u`` [T, B, A, 2] (and ``noise_c`` [T, B, A, dim_c] for speaking agents; T may be omitted for a single
+        step): the draws of the NEXT launch only, e.g. the reference's own, after which the generator takes over."""
+        draws = None
+        if noise_u is not None:
+            A, B, lo = self.n_agents, self.n_envs, self.layout
+            nu = torch.as_tensor(np.asarray(noise_u), dtype=self.dtype).reshape(-1, B, 2 * A)
+            T = nu.shape[0]
+            parts = [nu]
+            if lo.n_speakers > 0:
+                nc = torch.zeros(T, B, A, lo.dim_c, dtype=self.dtype) if noise_c is None else \
+                    torch.as_tensor(np.asarray(noise_c), dtype=self.dtype).reshape(T, B, A, lo.dim_c)
+                speakers = [i for i in range(A) if not self.spec.silent[i]]
+                parts.append(nc[:, :, speakers, :].reshape(T, B, -1))
+            row = torch.cat(parts, dim=2)
+            if row.shape[2] % 2:
+                row = torch.cat([row, torch.zeros(T, B, 1, dtype=self.dtype)], dim=2)
+            draws = self._noise_draws = row.contiguous().to(self.device)        # kept alive until the next call
+        _lib.check(self._h, self._lib.mpe_set_noise(self._h, int(seed), _ptr(draws)))
+
     def post_step(self):
         """Scenario.post_step alone (simple_predator_prey, collector): pick-ups, hand-overs and respawns on the
         current state, as ``step`` applies them after the callbacks.  Rewrites landmark positions and ``aux``."""

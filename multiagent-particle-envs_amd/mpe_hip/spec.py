@@ -41,6 +41,9 @@ class WorldSpec:
     # accel [A] is Agent.accel with nan for None (it scales the action force, new_core.py:214)
     new_core: bool = False
     accel: np.ndarray = None
+    # Agent.u_noise / Agent.c_noise [A], 0 for None (multiagent/core.py:165,211); no built-in scenario sets them
+    u_noise: np.ndarray = None
+    c_noise: np.ndarray = None
 
     def to_c(self):
         """Returns (MpeSpec, keepalive) -- keepalive owns the arrays the struct points into."""
@@ -59,6 +62,9 @@ class WorldSpec:
             arrs["ghost"] = u8(self.ghost, A)
         if self.new_core:
             arrs["accel"] = f64(np.full(A, np.nan) if self.accel is None else self.accel, A)
+        for name in ("u_noise", "c_noise"):
+            if getattr(self, name) is not None:
+                arrs[name] = f64(getattr(self, name), A)
         s = _lib.MpeSpec(scenario=self.scenario, n_agents=A, n_landmarks=self.n_landmarks, dim_c=self.dim_c,
                          dt=self.dt, damping=self.damping, contact_force=self.contact_force, contact_margin=self.contact_margin,
                          n_walls=W, collaborative=int(bool(self.collaborative)),

@@ -81,6 +81,10 @@ class Spec:
     # (:290-294); accel [A] holds Agent.accel with nan for None
     new_core: bool = False
     accel: Optional[np.ndarray] = None
+    # Agent.u_noise / Agent.c_noise [A] (core.py:85-87; None in the reference = 0 here): the standard deviation of
+    # the normal draws added to the action force (core.py:165) and to the comm state (core.py:211)
+    u_noise: Optional[np.ndarray] = None
+    c_noise: Optional[np.ndarray] = None
 
     @property
     def E(self) -> int:
@@ -371,22 +375,28 @@ def wall_force(spec: Spec, p, size, ghost, wall):
     return f, hit
 
 
-def world_step(spec: Spec, pos, vel, u, c):
-    """One World.step.  Returns new (pos, vel, comm); inputs are not modified."""
+def world_step(spec: Spec, pos, vel, u, c, noise_u=None, noise_c=None):
+    """One World.step.  Returns new (pos, vel, comm); inputs are not modified.
+
+    noise_u [B, A, 2] / noise_c [B, A, dim_c]: the standard-normal draws the reference takes with
+    np.random.randn for an agent whose u_noise / c_noise is set (core.py:165,211), passed in so that the
+    step stays a function of its arguments; they are scaled by spec.u_noise / spec.c_noise here."""
     A, E = spec.A, spec.E
     pos = np.array(pos, dtype=np.float64)
     vel = np.array(vel, dtype=np.float64)
     B = pos.shape[0]
-    # apply_action_force, core.py:161-167 (u_noise is None in scope -> + 0.0)
+    # apply_action_force, core.py:161-167: noise = randn(2) * u_noise if u_noise else 0.0
     force: List[Optional[np.ndarray]] = [None] * E
     for i in range(A):
         if spec.movable[i]:
+            un = spec.u_noise[i] if spec.u_noise is not None else 0.0
+            noise = noise_u[:, i, :] * un if un else 0.0
             if spec.new_core:                           # new_core.py:214
                 acc = spec.accel[i] if spec.accel is not None else np.nan
                 scale = spec.mass[i] * acc if not np.isnan(acc) else spec.mass[i]
-                force[i] = scale * u[:, i, :] + 0.0
+                force[i] = scale * u[:, i, :] + noise
             else:
-                force[i] = u[:, i, :] + 0.0
+                force[i] = u[:, i, :] + noise
     # apply_environment_force, core.py:170-181
     for a in range(E):
         for b in range(a + 1, E):
@@ -438,7 +448,8 @@ def world_step(spec: Spec, pos, vel, u, c):
     comm = np.zeros((B, A, spec.dim_c))
     for i in range(A):
         if not spec.silent[i]:
-            comm[:, i, :] = c[:, i, :] + 0.0
+            cn = spec.c_noise[i] if spec.c_noise is not None else 0.0
+            comm[:, i, :] = c[:, i, :] + (noise_c[:, i, :] * cn if cn else 0.0)      # core.py:211
     return pos, vel, comm
 
 
@@ -778,7 +789,7 @@ def share(spec: Spec, rew):
     return np.repeat(total[:, None], spec.A, axis=1)
 
 
-def env_step(spec: Spec, pos, vel, actions, goal=None):
+def env_step(spec: Spec, pos, vel, actions, goal=None, noise_u=None, noise_c=None):
     """MultiAgentEnv.step, multiagent/environment.py:83-115, for B envs.
 
     Returns (pos, vel, comm, obs_list, rew [B, A], done [B] bool); rew is what step returns, i.e.
@@ -787,7 +798,7 @@ def env_step(spec: Spec, pos, vel, actions, goal=None):
     (environment.py:143-146).
     """
     u, c = decode_actions(spec, actions)
-    pos, vel, comm = world_step(spec, pos, vel, u, c)
+    pos, vel, comm = world_step(spec, pos, vel, u, c, noise_u, noise_c)
     obs = observe(spec, pos, vel, comm, goal)
     rew = share(spec, reward(spec, pos, goal, comm))
     return pos, vel, comm, obs, rew, np.zeros(pos.shape[0], bool)
@@ -1005,6 +1016,35 @@ def device_reset_draw(seed, b, episode, e, lim, attempt=0):
 def device_aux_words(seed, b, episode):
     """The block the landmark indices / stream key of world(s) b come from: counter (b, episode * 256 + 255)."""
     return philox4x32(seed, b, np.uint64(episode * 256 + 255))
+
+
+def device_noise_pair(seed, b, step, k):
+    """Standard-normal pair k of world b at step number `step` of the device's noise stream: Box-Muller on the
+    Philox block with key seed ^ "noise" and counter (b, step * 256 + k).  b may be an array."""
+    r = philox4x32(np.uint64(0x6E6F697365000000) ^ np.uint64(seed), b, np.uint64(step) * np.uint64(256) + np.uint64(k))
+    u1 = 1.0 - _u01(r[..., 0], r[..., 1])         # (0, 1]
+    u2 = _u01(r[..., 2], r[..., 3])
+    rad = np.sqrt(-2.0 * np.log(u1))
+    return rad * np.cos(2.0 * np.pi * u2), rad * np.sin(2.0 * np.pi * u2)
+
+
+def device_noise(spec: Spec, seed, step, B):
+    """(noise_u [B, A, 2], noise_c [B, A, dim_c]) of step number `step`: pair i is agent i's force noise, the
+    comm values of the speakers follow in agent order, packed two to a pair from pair A on."""
+    b = np.arange(B, dtype=np.uint64)
+    nu = np.zeros((B, spec.A, 2))
+    nc = np.zeros((B, spec.A, spec.dim_c))
+    for i in range(spec.A):
+        nu[:, i, 0], nu[:, i, 1] = device_noise_pair(seed, b, step, i)
+    j = 0
+    for i in range(spec.A):
+        if spec.silent[i]:
+            continue
+        for c in range(spec.dim_c):
+            pair = device_noise_pair(seed, b, step, spec.A + j // 2)
+            nc[:, i, c] = pair[j % 2]
+            j += 1
+    return nu, nc
 
 
 def device_respawn_draw(key, b, n, lim=0.95):

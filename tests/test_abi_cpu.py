@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_mirrors_match_header_sizes():
     from mpe_hip import _lib
-    # MpeSpec: 4 int32 + 4 double + 9 pointers + 2 int32 + 7 pointers + 2 int32 + 1 pointer ; MpeLayout: int64 + 10 int32 + 2 * 64 int32
-    assert C.sizeof(_lib.MpeSpec) == 16 + 32 + 9 * 8 + 8 + 7 * 8 + 8 + 8
+    # MpeSpec: 4 int32 + 4 double + 9 pointers + 2 int32 + 7 pointers + 2 int32 + 3 pointers ; MpeLayout: int64 + 10 int32 + 2 * 64 int32
+    assert C.sizeof(_lib.MpeSpec) == 16 + 32 + 9 * 8 + 8 + 7 * 8 + 8 + 3 * 8
     assert C.sizeof(_lib.MpeLayout) == 8 + 10 * 4 + 2 * 64 * 4 + 8
 
 

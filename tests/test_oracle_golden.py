@@ -297,3 +297,36 @@ def test_oracle_reproduces_reference_gae():
         acc = delta[t] + 0.9 * 0.8 * acc
         want[t] = acc
     assert np.allclose(a1, want, rtol=1e-5, atol=1e-5)
+
+
+def noise_spec(g):
+    spec = orc.make_spec("simple_world_comm")
+    spec.u_noise, spec.c_noise = g["u_noise"].copy(), g["c_noise"].copy()
+    return spec
+
+
+def test_oracle_reproduces_reference_action_and_comm_noise():
+    """Agent.u_noise / c_noise (core.py:165,211): the reference's World.step with its own np.random.randn draws,
+    which the fixture stores; the oracle takes the draws as arguments and must land on the same bits."""
+    g = load_golden("noise")
+    spec = noise_spec(g)
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    assert np.abs(g["noise_u"][:, :, [2, 5]]).max() == 0 and np.abs(g["noise_u"][:, :, 0]).min() > 0     # only where u_noise is set
+    for t in range(g["actions"].shape[0]):
+        pos, vel, comm, obs, rew, _ = orc.env_step(spec, pos, vel, g["actions"][t], noise_u=g["noise_u"][t], noise_c=g["noise_c"][t])
+        assert np.array_equal(pos[:, :spec.A], g["pos"][t]) and np.array_equal(vel, g["vel"][t]), t
+        assert np.array_equal(comm[:, 0, :], g["comm"][t]), t
+        assert np.array_equal(np.concatenate(obs, axis=1), g["obs"][t]) and np.array_equal(rew, g["rew"][t]), t
+    # the noise matters: without it the trajectory is another one
+    p2, v2, *_ = orc.env_step(orc.make_spec("simple_world_comm"), g["pos0"], g["vel0"], g["actions"][0])
+    assert np.abs(p2[:, :spec.A] - g["pos"][0]).max() > 1e-3
+
+
+def test_device_noise_stream_is_standard_normal():
+    spec = noise_spec(load_golden("noise"))
+    nu, nc = orc.device_noise(spec, seed=5, step=3, B=20000)
+    for z in (nu.reshape(-1), nc[:, 0].reshape(-1)):
+        assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and abs((z ** 3).mean()) < 0.05
+    assert not nc[:, 1:].any()                                  # silent agents draw nothing
+    nu2, _ = orc.device_noise(spec, seed=5, step=4, B=8)
+    assert not np.array_equal(nu[:8], nu2)

@@ -917,6 +917,58 @@ def run_collector(ref, seed=20240661, B=32):
     return pos0, vel0, actions, rec
 
 
+def run_noise(ref, seed=20240681, B=8, T=10):
+    """simple_world_comm with Agent.u_noise / Agent.c_noise set: the noise terms of World.step (core.py:165,211),
+    which no built-in scenario switches on.  The reference draws them with np.random.randn from the global
+    generator; the generator is seeded per env, and a twin RandomState with the same seed, asked for the same
+    draws in the same order (movable agents with u_noise in agent order, then speakers with c_noise), gives the
+    draws the fixture stores next to the trajectory."""
+    rng = np.random.RandomState(seed)
+    pos0, vel0, actions = init_world_comm(rng)                  # 32 envs; the first B are used
+    pos0, vel0, actions = pos0[:B], vel0[:B], actions[:T, :B]
+    sc, world, env = make_env(ref, "simple_world_comm")
+    A, dim_c = len(world.agents), world.dim_c
+    u_noise = np.array([0.3, 0.1, 0.0, 0.2, 0.5, 0.0])
+    c_noise = np.array([0.25, 0.0, 0.0, 0.0, 0.0, 0.0])
+    for ag, un, cn in zip(world.agents, u_noise, c_noise):
+        ag.u_noise = float(un) if un else None
+        ag.c_noise = float(cn) if cn else None
+    dims = [s.shape[0] for s in env.observation_space]
+    rec = {"pos0": pos0, "vel0": vel0, "actions": actions, "u_noise": u_noise, "c_noise": c_noise,
+           "noise_u": np.zeros((T, B, A, 2)), "noise_c": np.zeros((T, B, A, dim_c)),
+           "pos": np.zeros((T, B, A, 2)), "vel": np.zeros((T, B, A, 2)), "comm": np.zeros((T, B, dim_c)),
+           "obs": np.zeros((T, B, sum(dims))), "rew": np.zeros((T, B, A)), "obs_dims": np.array(dims, np.int64)}
+    for b in range(B):
+        sc.reset_world(world)
+        inject(world, pos0[b], vel0[b])
+        np.random.seed(seed + 1 + b)
+        twin = np.random.RandomState(seed + 1 + b)
+        for t in range(T):
+            act = actions[t, b]
+            leader = world.agents[0]
+            leader.action.u = _move_u(int(act[0]), leader.accel)        # environment.py:176-181,192-195
+            c = np.zeros(dim_c)
+            c[int(act[1])] = 1.0                                        # environment.py:199-201
+            leader.action.c = c
+            for i in range(1, A):
+                env._set_action(int(act[1 + i]), world.agents[i], env.action_space[i])
+            world.step()
+            for i, ag in enumerate(world.agents):                       # the draws of apply_action_force
+                if ag.movable and ag.u_noise:
+                    rec["noise_u"][t, b, i] = twin.randn(2)
+            for i, ag in enumerate(world.agents):                       # the draws of update_agent_state
+                if not ag.silent and ag.c_noise:
+                    rec["noise_c"][t, b, i] = twin.randn(dim_c)
+            for i, ag in enumerate(world.agents):
+                rec["pos"][t, b, i], rec["vel"][t, b, i] = ag.state.p_pos, ag.state.p_vel
+            rec["comm"][t, b] = leader.state.c
+            rec["obs"][t, b] = np.concatenate([np.asarray(sc.observation(ag, world), np.float64) for ag in world.agents])
+            rec["rew"][t, b] = [float(sc.reward(ag, world)) for ag in world.agents]
+        # the twin has been asked for exactly the draws the reference took: both generators now agree
+        assert np.random.randn() == twin.randn()
+    return rec
+
+
 def run_gae(ref, seed=20240671):
     """Advantages and returns from the reference's own Runner.run (multiagent/backup/runner_old.py:39-80,
     the nenv > 1 branch): the runner is driven with a scripted env and model that replay fixed rewards,
@@ -1069,6 +1121,7 @@ def main():
                             actions=actions.astype(np.int32), **rec)
         print("wrote", path, os.path.getsize(path), "bytes")
     np.savez_compressed(os.path.join(OUT, "gae.npz"), **run_gae(ref))
+    np.savez_compressed(os.path.join(OUT, "noise.npz"), **run_noise(ref))
     print("wrote gae.npz")
     walls = run_walls(ref)
     np.savez_compressed(os.path.join(OUT, "walls.npz"), **walls)

@@ -20,8 +20,8 @@ for k in notes.split("- .agpr_count:")[1:]:
     rows.append((g("name"), int(k.split()[0]), int(g("vgpr_count")), int(g("vgpr_spill_count")), int(g("sgpr_spill_count")),
                  int(g("group_segment_fixed_size"))))
 names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.strip().split("\n")
-print("scenario, CLAMP, MODE, FULL, INFO, EPW | agpr vgpr(total) vgpr_spill sgpr_spill lds_bytes")
+print("scenario, CLAMP, MODE, FULL, INFO, EPW, NOISE | agpr vgpr(total) vgpr_spill sgpr_spill lds_bytes")
 for r, d in sorted(zip(rows, names), key=lambda x: x[1]):
-    m = re.match(r"void mpe::small_kernel<(\w+), mpe::(\w+)(?:<[^>]*>)?, (\w+), (\d), (\w+), (\w+), (\d+)>", d)
+    m = re.match(r"void mpe::small_kernel<(\w+), mpe::(\w+)(?:<[^>]*>)?, (\w+), (\d), (\w+), (\w+), (\d+), (\w+)>", d)
     if m and want in m.group(2):
         print(", ".join(m.groups()), "|", *r[1:])
