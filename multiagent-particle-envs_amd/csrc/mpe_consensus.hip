@@ -2,18 +2,13 @@
 // six non-colliding agents in the walled arena whose observations are the last ten positions and
 // velocities of their two ring neighbours relative to their own.
 //
-// One lane owns one world, one wave a tile of 64 worlds.  Positions and velocities (24 values) live
-// in registers; the history (240 values per world) stays in device memory as a ring of ten slots,
+// One lane owns one agent of one world, one wave ten worlds (60 lanes).  The history (240 values per
+// world) lives between launches in device memory as a ring of ten slots,
 // hist T[(slot * A + agent) * 4 + {px, py, vx, vy}][B], whose oldest slot is aux[0][b]: a step
 // overwrites the oldest slot with the new state and advances the head, which is what
 // World.integrate_state's vstack([his[1:], new]) does to the ordered history (new_core.py:252-254).
-// Rows are env-minor, so as long as the worlds of a wave share their head (they do unless they were
-// reset at different times) every history access is a coalesced 256-byte row.
-//
-// The observation of a world-step is 6 x 80 values; it is produced one agent at a time (a window of
-// three agents' histories in registers slides round the ring) into an
-// LDS tile of 64 x 80 (row stride 81: conflict-free row writes) and streamed to the env-major
-// output 4 bytes per lane, i.e. contiguous 256-byte runs.  Rewards leave through a small tile too.
+// Inside a launch a lane keeps what its agent observes -- the neighbours' history relative to its own --
+// in registers and only appends to the ring; see consensus_kernel.
 #include "mpe_launch.hpp"
 #include "mpe_math.hpp"
 
@@ -43,55 +38,126 @@ __host__ __device__ constexpr int nb_hi(int i) { return i == 0 ? CA - 1 : (i == 
 
 template <typename T> __device__ __forceinline__ T f32r(T v) { return (T)(float)v; }     // .astype(np.float32), consensus.py:140
 
-// MODE 0: mpe_step, 1: mpe_rollout / mpe_episode, 2: mpe_observe
+constexpr int WPW = 10;          // worlds per wave: lane = world * 6 + agent, lanes 60..63 idle
+constexpr int ROW = CA * COBS;   // observation values of one world-step
+
+template <typename T> __device__ __forceinline__ T lane_get(T v, int src);
+template <> __device__ __forceinline__ float lane_get<float>(float v, int src) { return __shfl(v, src, 64); }
+template <> __device__ __forceinline__ double lane_get<double>(double v, int src) { return __shfl(v, src, 64); }
+
+// MODE 0: mpe_step / mpe_step_auto, 1: mpe_rollout / mpe_episode(s), 2: mpe_observe
 // NOISE: agents with u_noise (its own instantiation: the generator is an out-of-line call)
+//
+// One lane owns one agent of one world.  What an agent observes -- its two ring neighbours' last ten
+// velocities and positions relative to its own at the same instants (80 values) -- is the lane's
+// register state R: a step shifts it by one instant and appends the new differences, for which the
+// lane fetches its neighbours' fresh position and velocity with four lane reads each.  The history
+// ring in device memory (the form the state has between launches) is read once at the start of a
+// launch and extended by one slot per step.  A wave's ten observation rows are contiguous in the
+// env-major output; the lanes write their 80 values into an LDS tile, which leaves as 16-byte vectors in
+// the order of those 19 200 bytes (float32), whole 128-byte lines.
 template <typename T, int MODE, bool NOISE = false>
 __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> p, const ResetArgs rs, const AutoArgs au, const NoiseArgs nz, const int* __restrict__ actions,
                                                        T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ hist_g,
                                                        int* __restrict__ aux_g, T* __restrict__ obs_g, T* __restrict__ rew_g,
                                                        uint8_t* __restrict__ done_g, T* __restrict__ obs0_g, int n_steps) {
-    __shared__ T tile_obs[64 * CSTRIDE];
-    __shared__ T tile_rew[64 * CA];
+    // Every lane's 80 values sit PAD apart: with the rows back to back (80 dwords) the lanes' 16-byte writes fall on
+    // 2 of the 8 four-bank groups, a 32-way conflict; at 84 they spread over all of them.
+    constexpr int PAD = COBS + 16 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(32))) T tile[WPW * CA * PAD];
     const int lane = threadIdx.x;
     const long long B = p.n_envs;
-    const long long env0 = (long long)blockIdx.x * 64;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Ten worlds' reward, done and
+    // history-slot stores are pieces of 128-byte lines that the neighbouring waves complete: waves that share
+    // an XCD take a contiguous range of the batch, so those pieces meet in one L2 and leave as whole lines.
+    // (A speed matter only: any placement gives the same result.)
+    const unsigned G = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned group = xcd * (G >> 3) + (xcd < (G & 7u) ? xcd : (G & 7u)) + idx;
+    const long long env0 = (long long)group * WPW;
     const long long left = B - env0;
-    const int nvalid = left < 64 ? (int)left : 64;
-    const bool valid = lane < nvalid;
-    const long long b = valid ? env0 + lane : env0;     // idle tail lanes shadow the wave's first env
+    const int nvalid = left < WPW ? (int)left : WPW;
+    // idle lanes (60..63, and the lanes of worlds beyond the batch) shadow the wave's first world: their
+    // loads are valid, their lane reads stay inside that world, and they store nothing
+    const int w_raw = lane / CA;
+    const bool valid = w_raw < nvalid;
+    const int w = valid ? w_raw : 0;
+    const int a = lane - w_raw * CA;
+    const long long b = env0 + w;
+    const int lane_lo = w * CA + nb_lo(a), lane_hi = w * CA + nb_hi(a);
 
-    auto hrow = [&](int slot, int i, int c) -> long long { return ((long long)((slot * CA + i) * 4 + c)) * B + b; };
+    auto hrow = [&](int slot, int c) -> long long { return ((long long)((slot * CA + a) * 4 + c)) * B + b; };
 
-    V2<T> pos[CA], vel[CA];
-    int head;
-    // reset_world, consensus.py:46-59: agents U(-1,1)^2 at rest, every history row equal to the start
-    auto reset_world = [&](const ResetArgs& r) {
-#pragma unroll
-        for (int i = 0; i < CA; ++i) {
-            const V2<double> d = reset_draw(r, (unsigned long long)b, i, true);
-            pos[i].x = (T)d.x; pos[i].y = (T)d.y;
-            vel[i].x = T(0); vel[i].y = T(0);
-        }
-        head = 0;
-        if (valid) {
-            for (int s = 0; s < CH; ++s)
-#pragma unroll
-                for (int i = 0; i < CA; ++i) {
-                    hist_g[hrow(s, i, 0)] = pos[i].x; hist_g[hrow(s, i, 1)] = pos[i].y;
-                    hist_g[hrow(s, i, 2)] = T(0); hist_g[hrow(s, i, 3)] = T(0);
+    V2<T> pos, vel;
+    int head = 0;
+    // R[g][k][d]: g 0 lower neighbour's velocity, 1 upper neighbour's velocity, 2 lower's position, 3 upper's
+    // position, each minus the agent's own, at instant k (oldest first), rounded as the observation is
+    // (.astype(np.float32), consensus.py:140): exactly the agent's 80 observation values, in order
+    T R[4][CH][2];
+    V2<T> dlo, dhi;             // unrounded offsets to the neighbours' current positions (reward)
+
+    // the neighbours' current state, and the differences the newest instant holds
+    auto newest = [&](T (&out)[4][2]) {
+        const T lvx = lane_get<T>(vel.x, lane_lo), lvy = lane_get<T>(vel.y, lane_lo);
+        const T hvx = lane_get<T>(vel.x, lane_hi), hvy = lane_get<T>(vel.y, lane_hi);
+        const T lpx = lane_get<T>(pos.x, lane_lo), lpy = lane_get<T>(pos.y, lane_lo);
+        const T hpx = lane_get<T>(pos.x, lane_hi), hpy = lane_get<T>(pos.y, lane_hi);
+        dlo.x = lpx - pos.x; dlo.y = lpy - pos.y;
+        dhi.x = hpx - pos.x; dhi.y = hpy - pos.y;
+        out[0][0] = f32r(lvx - vel.x); out[0][1] = f32r(lvy - vel.y);
+        out[1][0] = f32r(hvx - vel.x); out[1][1] = f32r(hvy - vel.y);
+        out[2][0] = f32r(dlo.x); out[2][1] = f32r(dlo.y);
+        out[3][0] = f32r(dhi.x); out[3][1] = f32r(dhi.y);
+    };
+    // reset_world, consensus.py:46-59: agents U(-1,1)^2 at rest, every history row equal to the start.
+    // Every lane of the wave must call it (it reads lanes); `mine` selects the worlds that are reset.
+    auto reset_world = [&](const ResetArgs& r, bool mine) {
+        if (mine) {
+            const V2<double> d = reset_draw(r, (unsigned long long)b, a, true);
+            pos.x = (T)d.x; pos.y = (T)d.y;
+            vel.x = T(0); vel.y = T(0);
+            head = 0;
+            if (valid) {
+                for (int s = 0; s < CH; ++s) {
+                    hist_g[hrow(s, 0)] = pos.x; hist_g[hrow(s, 1)] = pos.y;
+                    hist_g[hrow(s, 2)] = T(0); hist_g[hrow(s, 3)] = T(0);
                 }
+            }
+        }
+        T nw[4][2];
+        newest(nw);
+        if (mine) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < CH; ++k) { R[g][k][0] = nw[g][0]; R[g][k][1] = nw[g][1]; }
         }
     };
+
     if (MODE == 1 && rs.enabled) {
-        reset_world(rs);
+        reset_world(rs, true);
     } else {
-#pragma unroll
-        for (int i = 0; i < CA; ++i) {
-            pos[i].x = pos_g[(long long)(2 * i) * B + b]; pos[i].y = pos_g[(long long)(2 * i + 1) * B + b];
-            vel[i].x = vel_g[(long long)(2 * i) * B + b]; vel[i].y = vel_g[(long long)(2 * i + 1) * B + b];
-        }
+        pos.x = pos_g[(long long)(2 * a) * B + b]; pos.y = pos_g[(long long)(2 * a + 1) * B + b];
+        vel.x = vel_g[(long long)(2 * a) * B + b]; vel.y = vel_g[(long long)(2 * a + 1) * B + b];
         head = aux_g[b];
         head = (head < 0 || head >= CH) ? 0 : head;
+        // own history, oldest first, and from it and the neighbours' the relative history
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            int slot = head + k;
+            slot = slot >= CH ? slot - CH : slot;
+            T own[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) own[c] = hist_g[hrow(slot, c)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const T lo = lane_get<T>(own[c], lane_lo), hi = lane_get<T>(own[c], lane_hi);
+                const int g = (c < 2) ? 2 : 0;         // history rows hold (px, py, vx, vy)
+                R[g][k][c & 1] = f32r(lo - own[c]);
+                R[g + 1][k][c & 1] = f32r(hi - own[c]);
+            }
+        }
+        dlo.x = lane_get<T>(pos.x, lane_lo) - pos.x; dlo.y = lane_get<T>(pos.y, lane_lo) - pos.y;
+        dhi.x = lane_get<T>(pos.x, lane_hi) - pos.x; dhi.y = lane_get<T>(pos.y, lane_hi) - pos.y;
     }
 
     // Episode launches with obs0: the observation of every freshly reset state (what MultiAgentEnv.reset returns,
@@ -100,156 +166,148 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
     const bool want_obs0 = (MODE == 1) && rs.enabled && obs0_g != nullptr;
     bool pre = want_obs0;
     int t = 0, last_reset = 0;
+    // The agent's actions of the next NQ steps wait in a 4-bit queue (an int outside 1..4 is a no-op whatever its
+    // value, environment.py:176-181, so ints above 15 are held as 15): memory operations retire in issue
+    // order, and a load inside the step loop would wait for every store of the steps before it.
+    constexpr int NQ = (MODE == 1) ? 32 : 1;
+    unsigned long long q_lo = 0, q_hi = 0;
+    int q_left = 0;
+    auto refill = [&](int t0) {
+        unsigned raw[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const long long tt = (t0 + k < n_steps) ? t0 + k : n_steps - 1;     // past the end: re-read the last step
+            raw[k] = (unsigned)actions[(tt * B + b) * CA + a];
+        }
+        q_lo = q_hi = 0;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const unsigned long long v = raw[k] < 15u ? raw[k] : 15u;
+            if (k < 16) q_lo |= v << (4 * k);
+            else q_hi |= v << (4 * (k - 16));
+        }
+        q_left = NQ;
+    };
     while (t < n_steps) {
         const long long row = (long long)t * B + env0;
         if (MODE == 1 && rs.enabled && rs.period > 0 && t % rs.period == 0 && t != last_reset) {
             // next episode of a launch of several (mpe_episodes)
             ResetArgs nr = rs;
             nr.episode = rs.episode + (unsigned long long)(t / rs.period);
-            reset_world(nr);
+            reset_world(nr, true);
             last_reset = t;
             pre = want_obs0;
         }
         bool finished = false;
         if (MODE != 2 && !pre) {
             // ---- _set_action (environment.py:176-195) and World.step (new_core.py:188-205) ----
-#pragma unroll
-            for (int i = 0; i < CA; ++i) {
-                const int a = actions[((long long)t * B + b) * CA + i];
-                V2<T> f = decode_move<T>(a, p.sens);
-                f.x = p.force_scale * f.x; f.y = p.force_scale * f.y;           // new_core.py:214
-                if constexpr (NOISE) {                                          // + randn(2) * u_noise, new_core.py:213
-                    const V2<T> z = noise_pair<T>(nz, t, B, b, i);
-                    f.x = f.x + z.x * p.u_noise; f.y = f.y + z.y * p.u_noise;
-                }
-                // nothing collides (consensus.py:30); the walls act on every agent (:35-41, new_core.py:230-236)
-#pragma unroll
-                for (int w = 0; w < CW; ++w) {
-                    const T perp = p.wall_vertical[w] ? pos[i].x : pos[i].y;
-                    const T cut = (sizeof(T) == 4 ? T(18) : T(60)) * p.contact_margin;     // beyond it the softplus is 0 (float32) or < e^-60
-                    if (t_abs<T>(perp - p.wall_axis_pos[w]) - (p.size + T(0.5) * p.wall_width[w]) > cut) continue;
-                    V2<T> wf;
-                    if (wall_force_fast<T>(pos[i], p.size, p.ghost != 0, p.wall_vertical[w] != 0, p.wall_hard[w] != 0, p.wall_axis_pos[w],
-                                           p.wall_end0[w], p.wall_end1[w], p.wall_width[w], p.contact_force, p.contact_margin, wf)) {
-                        f.x = f.x + wf.x; f.y = f.y + wf.y;
-                    }
-                }
-                integrate<T, false>(pos[i], vel[i], f, p.mass, T(0), p.one_minus_damping, p.dt);
+            if (q_left == 0) refill(t);
+            const int act = (int)(q_lo & 15u);
+            q_lo = (q_lo >> 4) | (q_hi << 60);
+            q_hi >>= 4;
+            --q_left;
+            V2<T> f = decode_move<T>(act, p.sens);
+            f.x = p.force_scale * f.x; f.y = p.force_scale * f.y;           // new_core.py:214
+            if constexpr (NOISE) {                                          // + randn(2) * u_noise, new_core.py:213
+                const V2<T> z = noise_pair<T>(nz, t, B, b, a);
+                f.x = f.x + z.x * p.u_noise; f.y = f.y + z.y * p.u_noise;
             }
-            // the new state replaces the oldest history slot
-            if (valid) {
+            // nothing collides (consensus.py:30); the walls act on every agent (:35-41, new_core.py:230-236)
 #pragma unroll
-                for (int i = 0; i < CA; ++i) {
-                    hist_g[hrow(head, i, 0)] = pos[i].x; hist_g[hrow(head, i, 1)] = pos[i].y;
-                    hist_g[hrow(head, i, 2)] = vel[i].x; hist_g[hrow(head, i, 3)] = vel[i].y;
+            for (int wl = 0; wl < CW; ++wl) {
+                const T perp = p.wall_vertical[wl] ? pos.x : pos.y;
+                const T cut = (sizeof(T) == 4 ? T(18) : T(60)) * p.contact_margin;     // beyond it the softplus is 0 (float32) or < e^-60
+                if (t_abs<T>(perp - p.wall_axis_pos[wl]) - (p.size + T(0.5) * p.wall_width[wl]) > cut) continue;
+                V2<T> wf;
+                if (wall_force_fast<T>(pos, p.size, p.ghost != 0, p.wall_vertical[wl] != 0, p.wall_hard[wl] != 0, p.wall_axis_pos[wl],
+                                       p.wall_end0[wl], p.wall_end1[wl], p.wall_width[wl], p.contact_force, p.contact_margin, wf)) {
+                    f.x = f.x + wf.x; f.y = f.y + wf.y;
                 }
+            }
+            integrate<T, false>(pos, vel, f, p.mass, T(0), p.one_minus_damping, p.dt);
+            // the new state replaces the oldest history slot (new_core.py:252-254) ...
+            if (valid) {
+                hist_g[hrow(head, 0)] = pos.x; hist_g[hrow(head, 1)] = pos.y;
+                hist_g[hrow(head, 2)] = vel.x; hist_g[hrow(head, 3)] = vel.y;
             }
             head = (head + 1 == CH) ? 0 : head + 1;
+            // ... and the relative history moves on by one instant
+            T nw[4][2];
+            newest(nw);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int k = 0; k + 1 < CH; ++k) { R[g][k][0] = R[g][k + 1][0]; R[g][k][1] = R[g][k + 1][1]; }
+                R[g][CH - 1][0] = nw[g][0]; R[g][CH - 1][1] = nw[g][1];
+            }
         }
 
         // ---- reward(), consensus.py:91-113; shared by np.sum over the six agents (environment.py:103-105) ----
         const bool want_score = !pre && (MODE != 2 || rew_g != nullptr);
         if (want_score) {
-            T own[CA];
+            const T d0 = norm2<T>(dlo.x, dlo.y), d1 = norm2<T>(dhi.x, dhi.y);
+            T r = T(0) - (t_abs<T>(d0 - T(0.8)) + t_abs<T>(d1 - T(0.8))) * T(0.1);
+            const T r0 = r - t_abs<T>(norm2<T>(pos.x, pos.y) - T(0.8)) * T(0.1);
+            r = (a == 0) ? r0 : r;
+            r = r - T(2) * arena_bound<T>(t_abs<T>(pos.x));
+            r = r - T(2) * arena_bound<T>(t_abs<T>(pos.y));
+            T total = lane_get<T>(r, w * CA);
 #pragma unroll
-            for (int i = 0; i < CA; ++i) {
-                const int n0 = nb_lo(i), n1 = nb_hi(i);
-                const T d0 = norm2<T>(pos[n0].x - pos[i].x, pos[n0].y - pos[i].y);
-                const T d1 = norm2<T>(pos[n1].x - pos[i].x, pos[n1].y - pos[i].y);
-                T r = T(0) - (t_abs<T>(d0 - T(0.8)) + t_abs<T>(d1 - T(0.8))) * T(0.1);
-                if (i == 0) r = r - t_abs<T>(norm2<T>(pos[0].x, pos[0].y) - T(0.8)) * T(0.1);
-                r = r - T(2) * arena_bound<T>(t_abs<T>(pos[i].x));
-                r = r - T(2) * arena_bound<T>(t_abs<T>(pos[i].y));
-                own[i] = r;
-            }
-            T total = own[0];
-#pragma unroll
-            for (int i = 1; i < CA; ++i) total = total + own[i];
-#pragma unroll
-            for (int i = 0; i < CA; ++i) tile_rew[lane * CA + i] = (MODE == 2) ? own[i] : total;   // observe: what the callback returns
+            for (int i = 1; i < CA; ++i) total = total + lane_get<T>(r, w * CA + i);
+            const T out = (MODE == 2) ? r : total;        // observe: what the callback returns
             if (MODE == 0 && au.step_count != nullptr) {
                 // ---- episode bookkeeping (mpe_step_auto): returns, step counter, time-limit reset ----
                 T* ep = (T*)au.ep_return + b * CA;
                 const int cnt = au.step_count[b] + 1;
                 finished = cnt >= au.max_steps;
+                const int epi = au.episode_count[b] + 1;
+                // every lane of the world has read the counters before lane 0 of the world rewrites them
+                __syncthreads();
                 if (valid) {
-#pragma unroll
-                    for (int i = 0; i < CA; ++i) {
-                        const T sum = ep[i] + total;
-                        ep[i] = finished ? T(0) : sum;
-                        if (finished) ((T*)au.last_return)[b * CA + i] = sum;
+                    const T sum = ep[a] + total;
+                    ep[a] = finished ? T(0) : sum;
+                    if (finished) ((T*)au.last_return)[b * CA + a] = sum;
+                    if (a == 0) {
+                        au.step_count[b] = finished ? 0 : cnt;
+                        if (finished) au.episode_count[b] = epi;
                     }
-                    au.step_count[b] = finished ? 0 : cnt;
                 }
-                if (finished) {       // Scenario.reset_world with the next episode's draws; obs below is the fresh one
-                    const int epi = au.episode_count[b] + 1;
-                    if (valid) au.episode_count[b] = epi;
-                    reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0});
-                }
+                // Scenario.reset_world with the next episode's draws for the worlds that finished; obs below is the fresh one
+                reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0}, finished);
+            }
+            if (valid) {
+                rew_g[row * CA + lane] = out;
+                // no done callback (environment.py:143-146); mpe_step_auto flags the step that reaches its time limit
+                if (MODE != 2 && a == 0) done_g[row + w] = finished ? 1 : 0;
             }
         }
 
-        // ---- observation(), consensus.py:122-140, one agent at a time ----
-        // Agent i needs the histories of i - 1, i, i + 1: walking the ring in order, each step of the walk
-        // loads one more agent's 40 values and drops one (agent 5's stay for the end, agent 0's are
-        // fetched again for agent 5), 7 agent histories per world-step instead of 18.
+        // ---- observation(), consensus.py:122-140: the lane's 80 values into the image of the wave's rows ----
         {
-            T* const block = pre ? obs0_g + ((long long)(rs.period > 0 ? t / rs.period : 0) * B + env0) * (CA * COBS)
-                                 : obs_g + row * (CA * COBS);      // the wave's 64 rows of the env-major array
-            T H[CA][4 * CH];
-            auto load_agent = [&](int j) {
+            typedef T V4 __attribute__((ext_vector_type(4)));
+            V4* mine = reinterpret_cast<V4*>(tile + (w_raw * CA + a) * PAD);
+            if (lane < WPW * CA) {
 #pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    int slot = head + k;
-                    slot = slot >= CH ? slot - CH : slot;
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) H[j][4 * k + c] = hist_g[hrow(slot, j, c)];
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < CA; ++i) {
-                if (i == 0) { load_agent(CA - 1); load_agent(0); load_agent(1); }
-                else if (i + 1 < CA - 1) load_agent(i + 1);
-                else if (i == CA - 1) load_agent(0);
-                const int n0 = nb_lo(i), n1 = nb_hi(i);
-                T* orow = tile_obs + lane * CSTRIDE;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    const T* me = &H[i][4 * k];
-                    const T* lo = &H[n0][4 * k];
-                    const T* hi = &H[n1][4 * k];
-                    // [lo vel history (20), hi vel history (20), lo pos history (20), hi pos history (20)]
-                    orow[2 * k] = f32r(lo[2] - me[2]); orow[2 * k + 1] = f32r(lo[3] - me[3]);
-                    orow[2 * CH + 2 * k] = f32r(hi[2] - me[2]); orow[2 * CH + 2 * k + 1] = f32r(hi[3] - me[3]);
-                    orow[4 * CH + 2 * k] = f32r(lo[0] - me[0]); orow[4 * CH + 2 * k + 1] = f32r(lo[1] - me[1]);
-                    orow[6 * CH + 2 * k] = f32r(hi[0] - me[0]); orow[6 * CH + 2 * k + 1] = f32r(hi[1] - me[1]);
-                }
-                __syncthreads();
-                // stream the 64 x 80 tile out as 16-byte vectors (an agent's 80 values start on a 16-byte boundary
-                // of the row for both float types): vector g covers values [VEC * g, VEC * g + VEC) of row g / NVR
-                constexpr int VEC = 16 / (int)sizeof(T), NVR = COBS / VEC;
-                typedef T VT __attribute__((ext_vector_type(VEC)));
-                T* gbase = block + i * COBS;
+                    for (int k = 0; k < CH; k += 2) {
+                        V4 v;
+                        v[0] = R[g][k][0]; v[1] = R[g][k][1]; v[2] = R[g][k + 1][0]; v[3] = R[g][k + 1][1];
+                        mine[(g * CH + k) / 2] = v;
+                    }
+            }
+            __syncthreads();
+            T* const block = pre ? obs0_g + ((long long)(rs.period > 0 ? t / rs.period : 0) * B + env0) * ROW : obs_g + row * ROW;
+            // vector g of the wave's contiguous rows: values [VEC * g, + VEC) of agent-row g / NVA
+            constexpr int VEC = 16 / (int)sizeof(T), NV = WPW * ROW / VEC, NVR = ROW / VEC, NVA = COBS / VEC;
+            typedef T VT __attribute__((ext_vector_type(VEC)));
+            VT* dst = reinterpret_cast<VT*>(block);
+            const int nv = nvalid * NVR;
 #pragma unroll 4
-                for (int it = 0; it < NVR; ++it) {          // 64 * NVR vectors, 64 per iteration
-                    const int g = it * 64 + lane;
-                    const int r = g / NVR, j = (g - r * NVR) * VEC;
-                    VT v;
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) v[q] = tile_obs[r * CSTRIDE + j + q];
-                    if (r < nvalid) *reinterpret_cast<VT*>(gbase + (long long)r * (CA * COBS) + j) = v;
-                }
-                __syncthreads();
+            for (int g = lane; g < NV; g += 64) {
+                const int ar = g / NVA, j = g - ar * NVA;
+                if (g < nv) dst[g] = *reinterpret_cast<const VT*>(tile + ar * PAD + j * VEC);
             }
-        }
-        if (want_score) {
-            const int n = nvalid * CA;
-            for (int it = 0; it < CA; ++it) {
-                const int g = it * 64 + lane;
-                if (g < n) rew_g[row * CA + g] = tile_rew[g];
-            }
-            // no done callback (environment.py:143-146); mpe_step_auto flags the step that reaches its time limit
-            if (MODE != 2 && valid) done_g[row + lane] = finished ? 1 : 0;
             __syncthreads();
         }
         if (pre) pre = false;
@@ -257,12 +315,9 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
     }
 
     if (MODE != 2 && valid) {
-#pragma unroll
-        for (int i = 0; i < CA; ++i) {
-            pos_g[(long long)(2 * i) * B + b] = pos[i].x; pos_g[(long long)(2 * i + 1) * B + b] = pos[i].y;
-            vel_g[(long long)(2 * i) * B + b] = vel[i].x; vel_g[(long long)(2 * i + 1) * B + b] = vel[i].y;
-        }
-        aux_g[b] = head;
+        pos_g[(long long)(2 * a) * B + b] = pos.x; pos_g[(long long)(2 * a + 1) * B + b] = pos.y;
+        vel_g[(long long)(2 * a) * B + b] = vel.x; vel_g[(long long)(2 * a + 1) * B + b] = vel.y;
+        if (a == 0) aux_g[b] = head;
     }
 }
 
@@ -302,7 +357,7 @@ ConsensusParams<T> make_consensus_params(const HostSpec& s, long long B) {
 template <typename T>
 hipError_t launch_consensus_t(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
     const auto p = make_consensus_params<T>(s, B);
-    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    const dim3 grid((unsigned)((B + WPW - 1) / WPW)), block(64);
     T *pos = (T*)a.pos, *vel = (T*)a.vel, *hist = (T*)a.comm, *obs = (T*)a.obs, *rew = (T*)a.rew;
     if (mode == 0 && a.noise.enabled)
         hipLaunchKernelGGL((consensus_kernel<T, 0, true>), grid, block, 0, st, p, a.reset, a.au, a.noise, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);

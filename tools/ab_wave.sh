@@ -11,7 +11,7 @@ for v in "$@"; do
 import json,sys
 v,rep=sys.argv[1:3]
 d=json.loads(open('gpurun_out/ab_%s_%s.json'%(v,rep)).read().strip().splitlines()[-1])
-print(v, rep, "%.4f ms" % d['roofline']['launch_ms_hip_events'], "frac %.3f" % d['roofline']['frac'], flush=True)
+print(v, rep, "%.4f ms" % d['roofline']['launch_ms'], "frac %.3f" % d['roofline']['frac'], flush=True)
 PY
 done
 done
