@@ -50,6 +50,13 @@ struct CfgBase {
     // in pass k the lanes of worlds [k * 64 / R, (k + 1) * 64 / R) write their whole rows into a tile of 64 / R
     // rows, which leaves as contiguous 16-byte vectors (for rows too long to hold 64 of them in LDS)
     static constexpr int OBS_ROW_PASSES = 0;
+    // OBS_COOP: for the observation the wave regroups: in each of 8 passes its lanes are (8 worlds) x (A agents, A <= 8),
+    //   every lane runs observe_agent(its agent, its pass's world) once, and the pass's 8 whole rows leave as
+    //   contiguous 16-byte vectors.  The arithmetic is that of one observe_agent per agent and world, the stores are
+    //   whole lines.  The world's state is staged in LDS (StagedRows); what observe_prepare returns and the aux words
+    //   travel from the world's own lane by lane reads (ctx_from_lane).
+    static constexpr bool OBS_COOP = false;
+    template <class Ctx> __device__ __forceinline__ static Ctx ctx_from_lane(const Ctx& c, int) { return c; }
     __host__ __device__ __forceinline__ static constexpr bool movable(int) { return true; }    // Agent.movable
     __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
     // Entity whose magnitudes (size, mass, sensitivity, speed limit ...) entity e shares: a scenario whose
@@ -78,6 +85,25 @@ struct Staged {
         for (int e = 0; e < E; ++e) { base[(2 * e) * 64 + lane] = p[e].x; base[(2 * e + 1) * 64 + lane] = p[e].y; }
 #pragma unroll
         for (int i = 0; i < A; ++i) { base[(2 * E + 2 * i) * 64 + lane] = w[i].x; base[(2 * E + 2 * i + 1) * 64 + lane] = w[i].y; }
+    }
+};
+
+// The same staging world-major: world (lane) l keeps its values at l * STRIDE + v, STRIDE odd, so that lanes reading
+// different values of ONE world (the cooperative observation passes) and lanes writing their own world are both
+// conflict-free.
+template <typename T, int E, int A>
+struct StagedRows {
+    static constexpr int STRIDE = (2 * E + 2 * A) | 1;
+    static constexpr int SIZE = STRIDE * 64;
+    T* base;
+    int lane;       // the world's column
+    __device__ __forceinline__ V2<T> pos(int e) const { V2<T> v; v.x = base[lane * STRIDE + 2 * e]; v.y = base[lane * STRIDE + 2 * e + 1]; return v; }
+    __device__ __forceinline__ V2<T> vel(int i) const { V2<T> v; v.x = base[lane * STRIDE + 2 * E + 2 * i]; v.y = base[lane * STRIDE + 2 * E + 2 * i + 1]; return v; }
+    __device__ __forceinline__ void put(const V2<T> (&p)[E], const V2<T> (&w)[A]) const {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { base[lane * STRIDE + 2 * e] = p[e].x; base[lane * STRIDE + 2 * e + 1] = p[e].y; }
+#pragma unroll
+        for (int i = 0; i < A; ++i) { base[lane * STRIDE + 2 * E + 2 * i] = w[i].x; base[lane * STRIDE + 2 * E + 2 * i + 1] = w[i].y; }
     }
 };
 
@@ -745,8 +771,9 @@ struct PredatorPreyCfg : CfgBase {
     __host__ __device__ __forceinline__ static constexpr bool member(int i) { return i >= MEMBER0; }
     // adversaries, good agents, the barrier, foods and forests each share their properties (:39-41,49,58,67)
     __host__ __device__ __forceinline__ static constexpr int rep(int e) { return e < N_ADV ? 0 : (e < A ? N_ADV : (e == BARRIER ? BARRIER : (e < FOREST0 ? FOOD0 : FOREST0))); }
-    // a 64 x 315 tile (80 KB in float32) would leave one wave per CU: 16 whole rows at a time
-    static constexpr int OBS_ROW_PASSES = 4;
+    // a 64 x 315 tile (80 KB in float32) would leave one wave per CU: 8 whole rows at a time, the lanes regrouped
+    // as 8 worlds x 7 agents (8 lanes idle during the observation)
+    static constexpr bool OBS_COOP = true;
     __host__ __device__ __forceinline__ static constexpr int chunk_width(int) { return OBS_DIM; }
     __host__ __device__ __forceinline__ static constexpr int chunk_offset(int c) { return c * OBS_DIM; }
 
@@ -785,8 +812,49 @@ struct PredatorPreyCfg : CfgBase {
         return ObsCtx{bits, (unsigned)vis, (unsigned)(vis >> 32)};
     }
 
-    // observation() :300-349 of agents [I0, I1); offsets are cached_dist_vect[agent, other] = p_agent - p_other;
-    // cast to float32
+    __device__ __forceinline__ static ObsCtx ctx_from_lane(const ObsCtx& c, int src) {
+        return ObsCtx{__shfl(c.forest, src, 64), (unsigned)__shfl((int)c.vis_lo, src, 64), (unsigned)__shfl((int)c.vis_hi, src, 64)};
+    }
+
+    // observation() :300-349 of agent i (a run-time index) of the world staged in `w`; offsets are
+    // cached_dist_vect[agent, other] = p_agent - p_other; cast to float32
+    template <typename T, class Staging>
+    __device__ static __forceinline__ void observe_agent(int i, const Staging& w, const int* aux, const ObsCtx& ctx, T* row) {
+        const int flags = aux[0];
+        const unsigned long long visbits = ((unsigned long long)ctx.vis_hi << 32) | ctx.vis_lo;
+        const unsigned seen = (unsigned)(visbits >> (A * i)) & ((1u << A) - 1u);      // bit j: agent i sees agent j
+        const V2<T> me = w.pos(i), mv = w.vel(i);
+        row[0] = round_f32(mv.x); row[1] = round_f32(mv.y);
+        row[2] = round_f32(me.x); row[3] = round_f32(me.y);
+        int k = 4;
+        if (i >= MEMBER0) { row[4] = holds(flags, i) ? T(1) : T(-1); k = 5; }
+#pragma unroll
+        for (int n = 0; n < A - 1; ++n) {
+            const int j = n + (n >= i ? 1 : 0);
+            const bool vis = (seen >> j) & 1u;
+            const V2<T> pj = w.pos(j), vj = w.vel(j);
+            row[k + 2 * n] = vis ? round_f32(me.x - pj.x) : T(0);
+            row[k + 2 * n + 1] = vis ? round_f32(me.y - pj.y) : T(0);
+            row[k + 2 * (A - 1) + 2 * n] = vis ? round_f32(vj.x) : T(0);
+            row[k + 2 * (A - 1) + 2 * n + 1] = vis ? round_f32(vj.y) : T(0);
+        }
+        k += 4 * (A - 1);
+#pragma unroll
+        for (int j = MEMBER0; j < A; ++j) {
+            if (j == i) continue;
+            row[k++] = ((seen >> j) & 1u) ? (holds(flags, j) ? T(1) : T(-1)) : T(0);
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const V2<T> pl = w.pos(A + l);
+            row[k + 2 * l] = round_f32(me.x - pl.x); row[k + 2 * l + 1] = round_f32(me.y - pl.y);
+        }
+        k += 2 * L;
+        row[k] = ((ctx.forest >> (2 * i)) & 1) ? T(1) : T(-1);
+        row[k + 1] = ((ctx.forest >> (2 * i + 1)) & 1) ? T(1) : T(-1);
+    }
+
+    // observation() :300-349 of agents [I0, I1) with compile-time roles (mpe_observe's straight-line form)
     template <typename T, int I0, int I1>
     __device__ static __forceinline__ void observe_agents(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const int* aux, const ObsCtx& ctx, T* row) {
         int k = 0;
@@ -1041,11 +1109,11 @@ struct CollectorCfg : CfgBase {
     // sorted(zip(distance, index)): ascending distance, ties by index (collector.py:272-278)
     template <typename T> __device__ static __forceinline__ bool after(T ka, int ia, T kb, int ib) { return ka > kb || (ka == kb && ia > ib); }
 
-    static constexpr bool OBS_LOOP = true;
+    static constexpr bool OBS_COOP = true;
 
     // observation() of agent i (a run-time index), collector.py:268-295; cast to float32
-    template <typename T>
-    __device__ static __forceinline__ void observe_agent(int i, const Staged<T, E, A>& w, const int* aux, int, T* row) {
+    template <typename T, class Staging>
+    __device__ static __forceinline__ void observe_agent(int i, const Staging& w, const int* aux, int, T* row) {
         const int st = aux[0];
         const V2<T> me = w.pos(i), mv = w.vel(i);
         row[0] = round_f32(me.x); row[1] = round_f32(me.y);

@@ -163,14 +163,16 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     constexpr bool LIN = ((OW * (int)sizeof(T) / 4) % 16) != 0;
     constexpr int RP = Cfg::OBS_ROW_PASSES;                              // > 0: the tile holds EPW / RP whole rows at a time
     static_assert(RP == 0 || (Cfg::OBS_CHUNKS == 1 && !Cfg::OBS_LOOP && EPW % (RP > 0 ? RP : 1) == 0 && LIN), "row passes stream whole rows through a linear tile");
-    constexpr int TROWS = RP > 0 ? EPW / RP : EPW;
-    using ObsTile = Tile<T, OW, LIN, TROWS>;
+    constexpr bool COOP = Cfg::OBS_COOP;                                 // whole rows of 8 worlds per pass, lanes = worlds x agents
+    static_assert(!COOP || (EPW == 64 && A <= 8 && !Cfg::OBS_LOOP && RP == 0), "cooperative passes regroup a full wave as 8 worlds x up to 8 agents");
+    constexpr int TROWS = COOP ? 8 : (RP > 0 ? EPW / RP : EPW);
+    using ObsTile = Tile<T, (COOP ? OT : OW), (COOP ? true : LIN), TROWS>;
     using RewTile = Tile<T, A, true, EPW>;
     using IiTile = Tile<int, NI, true, EPW>;
     using IfTile = Tile<T, NF, true, EPW>;
     __shared__ __attribute__((aligned(16))) T tile_obs[ObsTile::SIZE];
     __shared__ __attribute__((aligned(16))) T tile_rew[RewTile::SIZE];
-    __shared__ T stage_lds[Cfg::OBS_LOOP ? Staged<T, E, A>::SIZE : 1];
+    __shared__ T stage_lds[Cfg::OBS_LOOP ? Staged<T, E, A>::SIZE : (COOP ? StagedRows<T, E, A>::SIZE : 1)];
     __shared__ __attribute__((aligned(16))) int tile_ii[INFO ? IiTile::SIZE : 4];
     __shared__ __attribute__((aligned(16))) T tile_if[INFO ? IfTile::SIZE : 4];
 
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                     }
                 }
             }
-            if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
+            if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
         }
         const long long row0 = (long long)t * B + env0;
         T* const obs_dst = pre ? obs0_g + (ep_idx * B + env0) * OT : obs_g + row0 * OT;
@@ -538,6 +540,32 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 }
                 __syncthreads();
             }
+        } else if constexpr (COOP) {
+            // Whole rows, TROWS = 8 worlds at a time, with the lanes regrouped as (world of the pass, agent): lane
+            // ag * 8 + k observes for agent ag in world pass * 8 + k, whose state it reads from the staging area and
+            // whose int state and per-step context it fetches from that world's lane (lanes beyond 8 * A idle).  One
+            // observe_agent per lane and pass: the same arithmetic as a loop over the agents, but the tile is a byte
+            // image of 8 consecutive rows and leaves as 16-byte vectors, whole 128-byte lines.
+            const StagedRows<T, E, A> own{stage_lds, lane};
+            own.put(pos, vel);
+            const auto ctx = Cfg::template observe_prepare<T>(pos, p);
+            __syncthreads();
+            const int k_in = lane % TROWS, ag = lane / TROWS;
+#pragma unroll 1
+            for (int pass = 0; pass < 64 / TROWS; ++pass) {
+                const int wl = pass * TROWS + k_in;
+                int auxw[NX > 0 ? NX : 1];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) auxw[k] = __shfl(aux[k], wl, 64);
+                const auto ctxw = Cfg::ctx_from_lane(ctx, wl);
+                const StagedRows<T, E, A> theirs{stage_lds, wl};
+                if (A == 8 || ag < A) Cfg::template observe_agent<T>(ag, theirs, auxw, ctxw, tile_obs + k_in * OT + Cfg::chunk_offset(ag));
+                __syncthreads();
+                int nv = nvalid - pass * TROWS;
+                nv = nv < 0 ? 0 : (nv > TROWS ? TROWS : nv);
+                ObsTile::template flush<FULL>(tile_obs, obs_dst + (long long)(pass * TROWS) * OT, lane, nv);
+                __syncthreads();
+            }
         } else if constexpr (RP > 0) {
             // Whole rows, TROWS worlds at a time: every lane evaluates the observation in each pass, the lanes of
             // the pass's worlds write their rows, and the tile -- a byte image of TROWS consecutive rows of the
@@ -569,7 +597,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
         // reset starts its episode untouched
         if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, (unsigned long long)b);
         __syncthreads();
-        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0) ObsTile::template flush<FULL>(tile_obs, obs_dst, lane, nvalid);
+        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) ObsTile::template flush<FULL>(tile_obs, obs_dst, lane, nvalid);
         if (want_score) {
             RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane, nvalid);
             if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
