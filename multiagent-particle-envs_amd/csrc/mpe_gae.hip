@@ -1,7 +1,8 @@
 // Generalised advantage estimation over a batch of rollouts, the step that follows the rollout in the
 // reference's training loop (multiagent/backup/runner_old.py:58-80): a backward scan over the steps of
-// every env.  One lane owns one env and walks t = T-1 .. 0; a wave's loads and stores of one step cover
-// 64 * A consecutive values (A passes over them when the agents are scanned one after another).  Inputs and outputs are float32 (the runner casts rewards and values to
+// every env.  A lane walks t = T-1 .. 0 for one env (the reference's scan, whose accumulator runs through the
+// env's agents) or for one (env, agent) element (independent scans: a wave's accesses of one step are then 64
+// consecutive values).  Inputs and outputs are float32 (the runner casts rewards and values to
 // float32, :61-62), the scan itself runs in float64 like the runner's (its `lastgaelam` stays a float64
 // array, the advantages are rounded to float32 when stored).
 #include "mpe_launch.hpp"
@@ -20,7 +21,10 @@ __global__ __launch_bounds__(256) void gae_kernel(long long B, int A, int T, con
                                                   const uint8_t* __restrict__ dones, const float* __restrict__ last_val,
                                                   const uint8_t* __restrict__ last_dones, double gamma, double lam,
                                                   float* __restrict__ adv, float* __restrict__ ret) {
-    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // MODE_REFERENCE: one lane per env (the chain runs through the env's agents).  MODE_STANDARD: one lane per
+    // (env, agent) element, so that a wave's accesses of one step are 64 consecutive values whatever A is.
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b = (MODE == MPE_GAE_REFERENCE) ? tid : tid / A;
     if (b >= B) return;
     const float gamma_f = (float)gamma;         // gamma * float32 array is a float32 product in numpy
     const double gl = gamma * lam;
@@ -43,17 +47,17 @@ __global__ __launch_bounds__(256) void gae_kernel(long long B, int A, int T, con
             for (int i = 0; i < A; ++i) chain = term(t, i, nnt, chain);
         }
     } else {
-        for (int i = 0; i < A; ++i) {
-            double chain = 0.0;
-            for (int t = T - 1; t >= 0; --t) chain = term(t, i, 1.0 - (double)dones[(long long)t * B + b], chain);
-        }
+        const int i = (int)(tid - b * A);
+        double chain = 0.0;
+        for (int t = T - 1; t >= 0; --t) chain = term(t, i, 1.0 - (double)dones[(long long)t * B + b], chain);
     }
 }
 
 template <int MODE>
 hipError_t launch_gae_mode(long long B, int A, int T, const float* rew, const float* val, const uint8_t* dones, const float* last_val,
                            const uint8_t* last_dones, double gamma, double lam, float* adv, float* ret, hipStream_t st) {
-    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    const long long lanes = (MODE == MPE_GAE_REFERENCE) ? B : B * A;
+    const dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
     hipLaunchKernelGGL((gae_kernel<MODE>), grid, block, 0, st, B, A, T, rew, val, dones, last_val, last_dones, gamma, lam, adv, ret);
     return hipGetLastError();
 }

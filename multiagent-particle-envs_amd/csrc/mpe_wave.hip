@@ -160,11 +160,6 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
         }
     };
 
-#ifdef MPE_STAGGER
-    // experiment: workgroups sharing a CU start out of phase, so that one's store burst meets another's arithmetic
-    if (EPI == EPI_SPREAD && MODE == WMODE_STEP && n_steps > 1 && ((((unsigned)blockIdx.x >> 3) ^ ((unsigned)blockIdx.x >> 8)) & 1u))
-        for (int k = 0; k < MPE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-#endif
     for (int t = 0; t < n_steps; ++t) {
         const long long row = (long long)t * B + b;
         if (EPI == EPI_SPREAD && MODE == WMODE_STEP && rs.enabled) {
