@@ -451,7 +451,7 @@ def main():
     mean_rew0 = tot["return_agent0"] / max(1.0, tot["episodes"])
 
     if rank == 0:
-        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()      # a one-GPU figure: rank 0 at N = 1 only
         if cpu is not None and args.cpu_procs > 1:
             cpu["n_process"] = cpu_baseline_processes(args.cpu_procs)
         value = world * B * A * timed_steps / elapsed
