@@ -171,6 +171,8 @@ class MultiAgentEnv:
             flat += self._action_ints(action_n[i], agent)
         sc.stage(world, ow)
         ow.step(flat)
+        if sc.rescore_after_step:
+            ow.observe(score=True, upload=False)
         world.t += 1
         pos, vel, comm = ow.state()
         world.unpack_state(pos[None], vel[None], None if comm is None else comm[None])

@@ -69,10 +69,13 @@ class OneWorld:
                                              p["rew"], p["done"], p["info_i"], p["info_f"], self._sp()))
         self._down()
 
-    def observe(self, score=True):
+    def observe(self, score=True, upload=True):
+        """The callbacks on the staged state, or with ``upload=False`` on the state the device already holds
+        (right after a step)."""
         env, p = self.env, self.env._p
         self._check_stream()
-        self._up()
+        if upload:
+            self._up()
         _lib.check(env._h, env._lib.mpe_observe(env._h, p["pos"], p["vel"], p["comm"], p["aux"], p["obs"], p["rew"] if score else None,
                                                 p["info_i"] if score else None, p["info_f"] if score else None, self._sp()))
         self._down()

@@ -50,6 +50,7 @@ class HipScenario(BaseScenario):
     fused_info = None        # ask the kernel for info_i / info_f (None: when has_info)
     fused_step = True        # MultiAgentEnv.step may run the whole step as one fused launch
     dynamic = False          # the scenario has a post_step (the kernel applies it: int state in aux, landmarks move)
+    rescore_after_step = False   # a step leaves only the shared reward: fetch the agents' own with mpe_observe on the new state
 
     def __init__(self):
         self._ow = None         # (signature, OneWorld)

@@ -3,9 +3,9 @@ only the neighbours' last ten positions and velocities relative to its own
 (multiagent/scenarios/consensus.py, on the physics of multiagent/new_core.py).
 
 The batched form (``BatchedEnv("consensus", ...)``) keeps the history as a ring in device memory and
-runs the whole step in one kernel.  This single-world plugin steps the world with the GPU physics
-(which slides ``state.p_his_pos`` / ``p_his_vel``) and evaluates the callbacks of all agents with one
-``mpe_observe`` launch.
+runs the whole step in one kernel.  So does this single-world plugin through ``MultiAgentEnv.step``: the
+world's state and history go up, one fused ``mpe_step`` launch, then one ``mpe_observe`` launch on the new
+state for the agents' own rewards (a step leaves only their sum), and everything comes down in one copy.
 """
 import numpy as np
 
@@ -20,7 +20,7 @@ class Scenario(HipScenario):
     obs_dtype = np.float32       # consensus.py:140
     has_info = True              # benchmark_data is defined (and constant: no landmarks, no collisions)
     fused_info = False
-    fused_step = False       # a step's rew is the shared sum; the agents' own rewards come from mpe_observe
+    rescore_after_step = True    # a step's rew is the shared sum; info_n['r<i>'] wants the agents' own rewards
 
     def make_world(self):
         world = World()

@@ -139,6 +139,7 @@ def test_drop_in_env_replays_the_reference():
     g = load_golden(CASE)
     env = mpe_hip.make_env(CASE, benchmark=True)
     assert env.shared_reward and env.n == 6
+    assert env._scenario is not None          # the step is the fused kernel (plus mpe_observe for the agents' own rewards)
     env.seed(0)
     env.reset()
     b = 20
