@@ -37,7 +37,7 @@ class BatchedEnv:
     """
 
     def __init__(self, scenario, n_envs, dtype=torch.float32, device="cuda:0", info=False, max_episode_steps=None, seed=0,
-                 **spec_kw):
+                 scripted=None, **spec_kw):
         self.spec = scenario if isinstance(scenario, WorldSpec) else make_spec(scenario, **spec_kw)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -64,6 +64,24 @@ class BatchedEnv:
             self.action_dims += ([5] if self.spec.movable[i] else []) + ([lo.dim_c] if not self.spec.silent[i] else [])
         self.obs_dims = [lo.obs_dim[i] for i in range(A)]
         self.obs_offsets = [lo.obs_offset[i] for i in range(A)]
+        # Scripted agents (Agent.action_callback, multiagent/core.py:144-147: World.step asks the callback for the
+        # agent's action, and MultiAgentEnv neither counts the agent in env.n nor takes an action for it,
+        # core.py:136-139, environment.py:21-23).  Batched form: scripted = {agent index: fn(env) -> int32 [B] or
+        # [B, k]}, the agent's action column(s) for every world, evaluated on the device tensors right before each
+        # step; step() then takes the policy agents' columns only.
+        self.scripted = dict(scripted or {})
+        cols, c = [], 0
+        for i in range(A):
+            k = (1 if self.spec.movable[i] else 0) + (0 if self.spec.silent[i] else 1)
+            cols.append(list(range(c, c + k)))
+            c += k
+        self.agent_cols = cols
+        for i in self.scripted:
+            if not 0 <= i < A or not cols[i]:
+                raise ValueError("scripted agent %r does not exist or takes no action" % (i,))
+        self.policy_cols = [c for i in range(A) if i not in self.scripted for c in cols[i]]
+        self.n_policy_act = len(self.policy_cols)
+        self._act_full = None
         # Every persistent buffer is a view into ONE zero-initialised device allocation (the arena), each on
         # a 256-byte boundary: inputs first (state, aux and -- for a one-world batch, whose caller stages
         # host data -- the action / force / comm-action slots), then the outputs.  A one-world caller can
@@ -161,6 +179,19 @@ class BatchedEnv:
         a = actions
         if not (torch.is_tensor(a) and a.dtype == torch.int32 and a.device == self.device and a.is_contiguous()):
             a = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
+        if self.scripted:
+            if lead:
+                raise ValueError("a multi-step launch takes pre-computed actions; scripted agents act on the state of every step")
+            if tuple(a.shape) != (self.n_envs, self.n_policy_act):
+                raise ValueError("actions must have shape %s (policy agents only), got %s" % ((self.n_envs, self.n_policy_act), tuple(a.shape)))
+            if self._act_full is None:
+                self._act_full = torch.zeros(self.n_envs, self.n_act, dtype=torch.int32, device=self.device)
+                self._policy_idx = torch.tensor(self.policy_cols, dtype=torch.long, device=self.device)
+            full = self._act_full
+            full[:, self._policy_idx] = a
+            for i, fn in self.scripted.items():
+                full[:, self.agent_cols[i]] = torch.as_tensor(fn(self), device=self.device).to(torch.int32).reshape(self.n_envs, -1)
+            return full
         want = tuple(lead) + (self.n_envs, self.n_act)
         if tuple(a.shape) != want:
             raise ValueError("actions must have shape %s, got %s" % (want, tuple(a.shape)))

@@ -557,3 +557,39 @@ def test_entry_points_leave_the_callers_device_current():
     env.step(torch.zeros(64, 3, dtype=torch.int32, device="cuda"))
     torch.cuda.synchronize()
     assert torch.cuda.current_device() == before
+
+
+def test_scripted_agents_act_from_the_state_of_every_step():
+    """Agent.action_callback in batched form (core.py:144-147): the scripted agent's action is computed on the device
+    from the current state before every step, the caller supplies the policy agents' actions only; the result is what
+    stepping with the full action array gives."""
+    import mpe_hip
+    B = 500
+
+    def flee(env):
+        # the good agent of simple_tag (agent 3) moves away from adversary 0 along the larger offset
+        d = env.pos[6:8] - env.pos[0:2]                     # [2, B]: p_3 - p_0 (env-minor rows 2e, 2e + 1)
+        along_x = d[0].abs() >= d[1].abs()
+        return torch.where(along_x, torch.where(d[0] >= 0, 2, 1), torch.where(d[1] >= 0, 4, 3)).to(torch.int32)
+
+    env = mpe_hip.BatchedEnv("simple_tag", B, dtype=torch.float64, scripted={3: flee})
+    ref = mpe_hip.BatchedEnv("simple_tag", B, dtype=torch.float64)
+    assert env.n_policy_act == 3 and env.policy_cols == [0, 1, 2] and ref.n_policy_act == 4
+    env.reset(seed=8)
+    ref.reset(seed=8)
+    gen = torch.Generator("cuda").manual_seed(4)
+    moved = 0
+    for t in range(10):
+        a = torch.randint(0, 5, (B, 3), dtype=torch.int32, device="cuda", generator=gen)
+        full = torch.cat([a, flee(ref).view(B, 1)], dim=1).contiguous()
+        moved += int((full[:, 3] != 0).sum())
+        o1, r1, _, _ = env.step(a)
+        o2, r2, _, _ = ref.step(full)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2), t
+    assert moved == 10 * B and torch.equal(env.pos, ref.pos)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(B, 4, dtype=torch.int32, device="cuda"))          # the scripted agent's column is not the caller's
+    with pytest.raises(ValueError):
+        env.rollout(torch.zeros(5, B, 3, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        mpe_hip.BatchedEnv("simple_tag", B, scripted={7: flee})
