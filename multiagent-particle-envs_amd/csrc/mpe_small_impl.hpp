@@ -774,38 +774,50 @@ static hipError_t launch_post_step(const HostSpec& s, long long B, const StepArg
 
 enum { MODE_POST_STEP = 3 };     // launch_small only: Scenario.post_step alone (a.pos, a.aux)
 
-template <typename T>
-hipError_t launch_small_t(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
+// The instantiations are spread over several translation units, (scenario group) x (float type), so that they
+// compile in parallel: mpe_small_<type>_<group>.hip each define one launch_small_<type>_<group>().
+enum { GROUP_CORE = 0,          // simple_spread 3/3, simple_tag, simple_world_comm
+       GROUP_CLASSIC = 1,       // simple, simple_adversary, simple_push, simple_speaker_listener, simple_reference, simple_crypto
+       GROUP_PREDATOR_PREY = 2,
+       GROUP_COLLECTOR = 3 };
+
+template <typename T, int GROUP>
+hipError_t launch_small_group(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
     if (mode == MODE_POST_STEP) {
-        if (s.scenario == MPE_SCN_PREDATOR_PREY) return launch_post_step<T, PredatorPreyCfg>(s, B, a, st);
-        if (s.scenario == MPE_SCN_COLLECTOR) return launch_post_step<T, CollectorCfg>(s, B, a, st);
+        if constexpr (GROUP == GROUP_PREDATOR_PREY) return launch_post_step<T, PredatorPreyCfg>(s, B, a, st);
+        if constexpr (GROUP == GROUP_COLLECTOR) return launch_post_step<T, CollectorCfg>(s, B, a, st);
         return hipErrorInvalidValue;
     }
-    const bool clamp = s.any_speed_limit();
-    switch (s.scenario) {
-        case MPE_SCN_SPREAD:
-            return clamp ? launch_cfg<T, SpreadCfg<3, 3>, true>(s, B, mode, a, st) : launch_cfg<T, SpreadCfg<3, 3>, false>(s, B, mode, a, st);
-        case MPE_SCN_TAG:
-            return launch_cfg<T, TagCfg, true>(s, B, mode, a, st);
-        case MPE_SCN_WORLD_COMM:
-            return launch_cfg<T, WorldCommCfg, true>(s, B, mode, a, st);
+    if constexpr (GROUP == GROUP_CORE) {
+        const bool clamp = s.any_speed_limit();
+        switch (s.scenario) {
+            case MPE_SCN_SPREAD:
+                return clamp ? launch_cfg<T, SpreadCfg<3, 3>, true>(s, B, mode, a, st) : launch_cfg<T, SpreadCfg<3, 3>, false>(s, B, mode, a, st);
+            case MPE_SCN_TAG:
+                return launch_cfg<T, TagCfg, true>(s, B, mode, a, st);
+            case MPE_SCN_WORLD_COMM:
+                return launch_cfg<T, WorldCommCfg, true>(s, B, mode, a, st);
+        }
+    } else if constexpr (GROUP == GROUP_CLASSIC) {
         // no speed limit in these scenarios; an infinite max_speed makes the clamp a no-op
-        case MPE_SCN_SIMPLE:
-            return launch_cfg<T, SimpleCfg, true>(s, B, mode, a, st);
-        case MPE_SCN_ADVERSARY:
-            return launch_cfg<T, AdversaryCfg, true>(s, B, mode, a, st);
-        case MPE_SCN_PUSH:
-            return launch_cfg<T, PushCfg, true>(s, B, mode, a, st);
-        case MPE_SCN_SPEAKER_LISTENER:
-            return launch_cfg<T, SpeakerListenerCfg, true>(s, B, mode, a, st);
-        case MPE_SCN_REFERENCE:
-            return launch_cfg<T, ReferenceCfg, true>(s, B, mode, a, st);
-        case MPE_SCN_CRYPTO:
-            return launch_cfg<T, CryptoCfg, true>(s, B, mode, a, st);
-        case MPE_SCN_PREDATOR_PREY:
-            return launch_cfg<T, PredatorPreyCfg, true>(s, B, mode, a, st);
-        case MPE_SCN_COLLECTOR:
-            return launch_cfg<T, CollectorCfg, true>(s, B, mode, a, st);
+        switch (s.scenario) {
+            case MPE_SCN_SIMPLE:
+                return launch_cfg<T, SimpleCfg, true>(s, B, mode, a, st);
+            case MPE_SCN_ADVERSARY:
+                return launch_cfg<T, AdversaryCfg, true>(s, B, mode, a, st);
+            case MPE_SCN_PUSH:
+                return launch_cfg<T, PushCfg, true>(s, B, mode, a, st);
+            case MPE_SCN_SPEAKER_LISTENER:
+                return launch_cfg<T, SpeakerListenerCfg, true>(s, B, mode, a, st);
+            case MPE_SCN_REFERENCE:
+                return launch_cfg<T, ReferenceCfg, true>(s, B, mode, a, st);
+            case MPE_SCN_CRYPTO:
+                return launch_cfg<T, CryptoCfg, true>(s, B, mode, a, st);
+        }
+    } else if constexpr (GROUP == GROUP_PREDATOR_PREY) {
+        if (s.scenario == MPE_SCN_PREDATOR_PREY) return launch_cfg<T, PredatorPreyCfg, true>(s, B, mode, a, st);
+    } else {
+        if (s.scenario == MPE_SCN_COLLECTOR) return launch_cfg<T, CollectorCfg, true>(s, B, mode, a, st);
     }
     return hipErrorInvalidValue;
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Registers, spills and LDS of every small_kernel instantiation in a device-only object.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off --cuda-device-only -c mpe_small_f32.hip -o /tmp/f32.co
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off --cuda-device-only -c mpe_small_f32_core.hip -o /tmp/f32.co
     python3 tools/kernel_resources.py /tmp/f32.co [substring of the scenario's Cfg name]
 """
 import re
