@@ -100,6 +100,28 @@ def test_full_batch_episode(scn, kw, B, dtype):
         assert np.array_equal(sc, comm1[:m])
 
 
+@pytest.mark.parametrize("scn,kw,B", CASES)
+def test_benchmark_launch_at_full_size_equals_its_parts(scn, kw, B):
+    """What bench.py times -- one launch per episode: on-device reset, the reset state's observation, 25 steps --
+    against mpe_reset + mpe_observe + mpe_rollout on a second batch, bit for bit, at the BASELINE batch sizes."""
+    import mpe_hip
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(9)
+    e1 = mpe_hip.BatchedEnv(scn, B, dtype=torch.float32, **kw)
+    actions = _actions(e1, scn, gen)
+    first = e1.reset(seed=1234).clone()
+    o1 = e1.rollout(actions)
+    want = {k: o1[k].clone() for k in ("obs", "rew", "done")}
+    pos, vel = e1.pos.clone(), e1.vel.clone()
+    del e1, o1
+    e2 = mpe_hip.BatchedEnv(scn, B, dtype=torch.float32, **kw)
+    o2 = e2.rollout(actions, reset_seed=1234, obs0=True)
+    assert torch.equal(o2["obs0"][0], first)
+    for k in want:
+        assert torch.equal(o2[k], want[k]), k
+    assert torch.equal(e2.pos, pos) and torch.equal(e2.vel, vel)
+
+
 def test_reset_is_reproducible_and_independent_of_batch_size():
     import mpe_hip
     a = mpe_hip.BatchedEnv("simple_tag", 131072, dtype=torch.float32)
