@@ -2,12 +2,12 @@
 // six non-colliding agents in the walled arena whose observations are the last ten positions and
 // velocities of their two ring neighbours relative to their own.
 //
-// One lane owns one agent of one world, one wave ten worlds (60 lanes).  The history (240 values per
+// One thread owns one agent of one world, a workgroup of 192 threads 32 worlds.  The history (240 values per
 // world) lives between launches in device memory as a ring of ten slots,
 // hist T[(slot * A + agent) * 4 + {px, py, vx, vy}][B], whose oldest slot is aux[0][b]: a step
 // overwrites the oldest slot with the new state and advances the head, which is what
 // World.integrate_state's vstack([his[1:], new]) does to the ordered history (new_core.py:252-254).
-// Inside a launch a lane keeps what its agent observes -- the neighbours' history relative to its own --
+// Inside a launch a thread keeps what its agent observes -- the neighbours' history relative to its own --
 // in registers and only appends to the ring; see consensus_kernel.
 #include "mpe_launch.hpp"
 #include "mpe_math.hpp"
@@ -38,69 +38,79 @@ __host__ __device__ constexpr int nb_hi(int i) { return i == 0 ? CA - 1 : (i == 
 
 template <typename T> __device__ __forceinline__ T f32r(T v) { return (T)(float)v; }     // .astype(np.float32), consensus.py:140
 
-constexpr int WPW = 10;          // worlds per wave: lane = world * 6 + agent, lanes 60..63 idle
+constexpr int WPG = 32;          // worlds per workgroup
+constexpr int NT = WPG * CA;     // its threads: thread = world * 6 + agent, three full waves
+constexpr int XS = WPG + 1;      // row stride of the exchange area (odd: a wave's writes spread over the banks)
 constexpr int ROW = CA * COBS;   // observation values of one world-step
-
-template <typename T> __device__ __forceinline__ T lane_get(T v, int src);
-template <> __device__ __forceinline__ float lane_get<float>(float v, int src) { return __shfl(v, src, 64); }
-template <> __device__ __forceinline__ double lane_get<double>(double v, int src) { return __shfl(v, src, 64); }
+constexpr int TROWS = 32;        // agent-rows a wave's tile holds (half of its 64 lanes' rows)
 
 // MODE 0: mpe_step / mpe_step_auto, 1: mpe_rollout / mpe_episode(s), 2: mpe_observe
 // NOISE: agents with u_noise (its own instantiation: the generator is an out-of-line call)
 //
-// One lane owns one agent of one world.  What an agent observes -- its two ring neighbours' last ten
-// velocities and positions relative to its own at the same instants (80 values) -- is the lane's
-// register state R: a step shifts it by one instant and appends the new differences, for which the
-// lane fetches its neighbours' fresh position and velocity with four lane reads each.  The history
-// ring in device memory (the form the state has between launches) is read once at the start of a
-// launch and extended by one slot per step.  A wave's ten observation rows are contiguous in the
-// env-major output; the lanes write their 80 values into an LDS tile, which leaves as 16-byte vectors in
-// the order of those 19 200 bytes (float32), whole 128-byte lines.
+// One thread owns one agent of one world, a workgroup of three waves 32 worlds: every store of a step then
+// covers whole 128-byte lines -- 32 worlds' rewards are 768 bytes, one history row of 32 worlds is 128 bytes, a
+// wave's 64 observation rows are 160 lines -- where ten worlds per wave left the rewards and the history slot in
+// 40-byte pieces that cost a seventh of the launch.  What an agent observes -- its two ring neighbours' last ten
+// velocities and positions relative to its own at the same instants (80 values) -- is the thread's register state
+// R: a step shifts it by one instant and appends the new differences.  The threads of a world may sit in two waves,
+// so they exchange their fresh position and velocity (and their reward terms) through LDS.  The history ring in
+// device memory (the form the state has between launches) is read once at the start of a launch; a step stores
+// its slot only if no later step of the launch overwrites it.  Each wave writes its lanes' 80 values into its own
+// LDS tile, 32 lanes at a time, which leaves as 16-byte vectors in the order of those 10 240 bytes (float32).
 template <typename T, int MODE, bool NOISE = false>
-__global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> p, const ResetArgs rs, const AutoArgs au, const NoiseArgs nz, const int* __restrict__ actions,
+__global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> p, const ResetArgs rs, const AutoArgs au, const NoiseArgs nz, const int* __restrict__ actions,
                                                        T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ hist_g,
                                                        int* __restrict__ aux_g, T* __restrict__ obs_g, T* __restrict__ rew_g,
                                                        uint8_t* __restrict__ done_g, T* __restrict__ obs0_g, int n_steps) {
     // Every lane's 80 values sit PAD apart: with the rows back to back (80 dwords) the lanes' 16-byte writes fall on
     // 2 of the 8 four-bank groups, a 32-way conflict; at 84 they spread over all of them.
     constexpr int PAD = COBS + 16 / (int)sizeof(T);
-    __shared__ __attribute__((aligned(32))) T tile[WPW * CA * PAD];
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(32))) T tiles[NT / 64][TROWS * PAD];
+    __shared__ T xch[CA * 4 * XS];       // [agent][px, py, vx, vy][world]: the newest state, also the history slot's image
+    __shared__ T rsum[NT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long B = p.n_envs;
-    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Ten worlds' reward, done and
-    // history-slot stores are pieces of 128-byte lines that the neighbouring waves complete: waves that share
-    // an XCD take a contiguous range of the batch, so those pieces meet in one L2 and leave as whole lines.
-    // (A speed matter only: any placement gives the same result.)
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: workgroups that share an XCD take a
+    // contiguous range of the batch (a speed matter for the stores that are pieces of lines -- single steps' history
+    // rows -- only: any placement gives the same result).
     const unsigned G = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
     const unsigned group = xcd * (G >> 3) + (xcd < (G & 7u) ? xcd : (G & 7u)) + idx;
-    const long long env0 = (long long)group * WPW;
+    const long long env0 = (long long)group * WPG;
     const long long left = B - env0;
-    const int nvalid = left < WPW ? (int)left : WPW;
-    // idle lanes (60..63, and the lanes of worlds beyond the batch) shadow the wave's first world: their
-    // loads are valid, their lane reads stay inside that world, and they store nothing
-    const int w_raw = lane / CA;
+    const int nvalid = left < WPG ? (int)left : WPG;
+    // the threads of worlds beyond the batch shadow the workgroup's first world: their loads are valid, they
+    // compute what that world's threads compute, and they store nothing
+    const int w_raw = tid / CA;
     const bool valid = w_raw < nvalid;
     const int w = valid ? w_raw : 0;
-    const int a = lane - w_raw * CA;
+    const int a = tid - w_raw * CA;
     const long long b = env0 + w;
-    const int lane_lo = w * CA + nb_lo(a), lane_hi = w * CA + nb_hi(a);
+    const int a_lo = nb_lo(a), a_hi = nb_hi(a);
 
     auto hrow = [&](int slot, int c) -> long long { return ((long long)((slot * CA + a) * 4 + c)) * B + b; };
 
     V2<T> pos, vel;
     int head = 0;
+    bool same_heads = (MODE == 1) && rs.enabled;       // every world reset by this launch at the same steps
     // R[g][k][d]: g 0 lower neighbour's velocity, 1 upper neighbour's velocity, 2 lower's position, 3 upper's
     // position, each minus the agent's own, at instant k (oldest first), rounded as the observation is
     // (.astype(np.float32), consensus.py:140): exactly the agent's 80 observation values, in order
     T R[4][CH][2];
     V2<T> dlo, dhi;             // unrounded offsets to the neighbours' current positions (reward)
 
-    // the neighbours' current state, and the differences the newest instant holds
+    // the thread's four values into the exchange area; readers wait for the barrier that follows
+    auto publish = [&](T px, T py, T vx, T vy) {
+        if (valid) {
+            xch[(a * 4 + 0) * XS + w] = px; xch[(a * 4 + 1) * XS + w] = py;
+            xch[(a * 4 + 2) * XS + w] = vx; xch[(a * 4 + 3) * XS + w] = vy;
+        }
+    };
+    // the neighbours' current state (published, barrier passed), and the differences the newest instant holds
     auto newest = [&](T (&out)[4][2]) {
-        const T lvx = lane_get<T>(vel.x, lane_lo), lvy = lane_get<T>(vel.y, lane_lo);
-        const T hvx = lane_get<T>(vel.x, lane_hi), hvy = lane_get<T>(vel.y, lane_hi);
-        const T lpx = lane_get<T>(pos.x, lane_lo), lpy = lane_get<T>(pos.y, lane_lo);
-        const T hpx = lane_get<T>(pos.x, lane_hi), hpy = lane_get<T>(pos.y, lane_hi);
+        const T lpx = xch[(a_lo * 4 + 0) * XS + w], lpy = xch[(a_lo * 4 + 1) * XS + w];
+        const T lvx = xch[(a_lo * 4 + 2) * XS + w], lvy = xch[(a_lo * 4 + 3) * XS + w];
+        const T hpx = xch[(a_hi * 4 + 0) * XS + w], hpy = xch[(a_hi * 4 + 1) * XS + w];
+        const T hvx = xch[(a_hi * 4 + 2) * XS + w], hvy = xch[(a_hi * 4 + 3) * XS + w];
         dlo.x = lpx - pos.x; dlo.y = lpy - pos.y;
         dhi.x = hpx - pos.x; dhi.y = hpy - pos.y;
         out[0][0] = f32r(lvx - vel.x); out[0][1] = f32r(lvy - vel.y);
@@ -109,22 +119,27 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
         out[3][0] = f32r(dhi.x); out[3][1] = f32r(dhi.y);
     };
     // reset_world, consensus.py:46-59: agents U(-1,1)^2 at rest, every history row equal to the start.
-    // Every lane of the wave must call it (it reads lanes); `mine` selects the worlds that are reset.
-    auto reset_world = [&](const ResetArgs& r, bool mine) {
+    // Every thread of the workgroup must call it (it holds barriers); `mine` selects the worlds that are reset.
+    // The ring in device memory is the state BETWEEN launches: slot k is rewritten by the k-th step after the
+    // reset, so only the slots from `keep_from` on -- those the rest of the launch does not reach -- are stored.
+    auto reset_world = [&](const ResetArgs& r, bool mine, int keep_from) {
         if (mine) {
             const V2<double> d = reset_draw(r, (unsigned long long)b, a, true);
             pos.x = (T)d.x; pos.y = (T)d.y;
             vel.x = T(0); vel.y = T(0);
             head = 0;
             if (valid) {
-                for (int s = 0; s < CH; ++s) {
+                for (int s = (keep_from > 0 ? keep_from : 0); s < CH; ++s) {
                     hist_g[hrow(s, 0)] = pos.x; hist_g[hrow(s, 1)] = pos.y;
                     hist_g[hrow(s, 2)] = T(0); hist_g[hrow(s, 3)] = T(0);
                 }
             }
         }
+        publish(pos.x, pos.y, vel.x, vel.y);
+        __syncthreads();
         T nw[4][2];
         newest(nw);
+        __syncthreads();        // the exchange area is rewritten by the next step
         if (mine) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -133,31 +148,66 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
         }
     };
 
+    // a single step's action is fetched with the state, not after it
+    const unsigned act0 = (MODE == 0 && n_steps > 0) ? (unsigned)actions[b * CA + a] : 0u;
     if (MODE == 1 && rs.enabled) {
-        reset_world(rs, true);
+        reset_world(rs, true, n_steps);
     } else {
         pos.x = pos_g[(long long)(2 * a) * B + b]; pos.y = pos_g[(long long)(2 * a + 1) * B + b];
         vel.x = vel_g[(long long)(2 * a) * B + b]; vel.y = vel_g[(long long)(2 * a + 1) * B + b];
         head = aux_g[b];
         head = (head < 0 || head >= CH) ? 0 : head;
         // own history, oldest first, and from it and the neighbours' the relative history
+        // Do the workgroup's worlds agree on the head (they do unless some were reset on their own)?  Then a step's
+        // history slot leaves as whole lines, as in an episode launch.
+        same_heads = __syncthreads_and(head == aux_g[env0]) != 0;
+        // The threads exchange their histories through the observation tiles, idle until the first observation:
+        // [instant][agent][px, py, vx, vy][world], all ten instants' loads in flight at once.
+        T* const xarea = &tiles[0][0];
+        constexpr int AXS = (CH * CA * 4 * XS <= (NT / 64) * TROWS * PAD) ? XS : WPG;       // float64: no room for the padding
+        static_assert(CH * CA * 4 * AXS <= (NT / 64) * TROWS * PAD, "ten instants of 32 worlds must fit the tiles");
+        if (same_heads) {
+            // the ten slots are 240 rows of 32 consecutive worlds: whole lines, two per wave and instruction
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            int slot = head + k;
-            slot = slot >= CH ? slot - CH : slot;
-            T own[4];
+            for (int i = 0; i < CH * CA * 4 * WPG / NT; ++i) {
+                const int j = i * NT + tid, kk = j / (CA * 4 * WPG), q = (j - kk * (CA * 4 * WPG)) / WPG, wj = j % WPG;
+                int slot = head + kk;
+                slot = slot >= CH ? slot - CH : slot;
+                xarea[(kk * CA * 4 + q) * AXS + wj] = hist_g[(long long)(slot * CA * 4 + q) * B + env0 + (wj < nvalid ? wj : 0)];
+            }
+        } else {
+            T own[CH][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) own[c] = hist_g[hrow(slot, c)];
+            for (int k = 0; k < CH; ++k) {
+                int slot = head + k;
+                slot = slot >= CH ? slot - CH : slot;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const T lo = lane_get<T>(own[c], lane_lo), hi = lane_get<T>(own[c], lane_hi);
-                const int g = (c < 2) ? 2 : 0;         // history rows hold (px, py, vx, vy)
-                R[g][k][c & 1] = f32r(lo - own[c]);
-                R[g + 1][k][c & 1] = f32r(hi - own[c]);
+                for (int c = 0; c < 4; ++c) own[k][c] = hist_g[hrow(slot, c)];
+            }
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xarea[((k * CA + a) * 4 + c) * AXS + w] = own[k][c];
             }
         }
-        dlo.x = lane_get<T>(pos.x, lane_lo) - pos.x; dlo.y = lane_get<T>(pos.y, lane_lo) - pos.y;
-        dhi.x = lane_get<T>(pos.x, lane_hi) - pos.x; dhi.y = lane_get<T>(pos.y, lane_hi) - pos.y;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const T own = xarea[((k * CA + a) * 4 + c) * AXS + w];
+                const T lo = xarea[((k * CA + a_lo) * 4 + c) * AXS + w], hi = xarea[((k * CA + a_hi) * 4 + c) * AXS + w];
+                const int g = (c < 2) ? 2 : 0;         // history rows hold (px, py, vx, vy)
+                R[g][k][c & 1] = f32r(lo - own);
+                R[g + 1][k][c & 1] = f32r(hi - own);
+            }
+        __syncthreads();
+        publish(pos.x, pos.y, vel.x, vel.y);
+        __syncthreads();
+        dlo.x = xch[(a_lo * 4 + 0) * XS + w] - pos.x; dlo.y = xch[(a_lo * 4 + 1) * XS + w] - pos.y;
+        dhi.x = xch[(a_hi * 4 + 0) * XS + w] - pos.x; dhi.y = xch[(a_hi * 4 + 1) * XS + w] - pos.y;
+        __syncthreads();
     }
 
     // Episode launches with obs0: the observation of every freshly reset state (what MultiAgentEnv.reset returns,
@@ -194,18 +244,23 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
             // next episode of a launch of several (mpe_episodes)
             ResetArgs nr = rs;
             nr.episode = rs.episode + (unsigned long long)(t / rs.period);
-            reset_world(nr, true);
+            reset_world(nr, true, n_steps - t);
             last_reset = t;
             pre = want_obs0;
         }
         bool finished = false;
         if (MODE != 2 && !pre) {
             // ---- _set_action (environment.py:176-195) and World.step (new_core.py:188-205) ----
-            if (q_left == 0) refill(t);
-            const int act = (int)(q_lo & 15u);
-            q_lo = (q_lo >> 4) | (q_hi << 60);
-            q_hi >>= 4;
-            --q_left;
+            int act;
+            if (MODE == 0 && t == 0) {
+                act = (int)(act0 < 15u ? act0 : 15u);
+            } else {
+                if (q_left == 0) refill(t);
+                act = (int)(q_lo & 15u);
+                q_lo = (q_lo >> 4) | (q_hi << 60);
+                q_hi >>= 4;
+                --q_left;
+            }
             V2<T> f = decode_move<T>(act, p.sens);
             f.x = p.force_scale * f.x; f.y = p.force_scale * f.y;           // new_core.py:214
             if constexpr (NOISE) {                                          // + randn(2) * u_noise, new_core.py:213
@@ -225,10 +280,23 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
                 }
             }
             integrate<T, false>(pos, vel, f, p.mass, T(0), p.one_minus_damping, p.dt);
-            // the new state replaces the oldest history slot (new_core.py:252-254) ...
-            if (valid) {
-                hist_g[hrow(head, 0)] = pos.x; hist_g[hrow(head, 1)] = pos.y;
-                hist_g[hrow(head, 2)] = vel.x; hist_g[hrow(head, 3)] = vel.y;
+            publish(pos.x, pos.y, vel.x, vel.y);
+            __syncthreads();
+            // the new state replaces the oldest history slot (new_core.py:252-254); a slot that a later step of this
+            // launch overwrites again is not stored ...
+            if (t + CH >= n_steps) {
+                if (same_heads) {
+                    // the heads agree: the exchange area is the slot's image, [agent][px, py, vx, vy] x 32 worlds, and
+                    // leaves as 24 whole lines
+#pragma unroll
+                    for (int i = 0; i < CA * 4 * WPG / NT; ++i) {
+                        const int j = i * NT + tid, r = j / WPG, wj = j - r * WPG;
+                        if (wj < nvalid) hist_g[(long long)(head * CA * 4 + r) * B + env0 + wj] = xch[r * XS + wj];
+                    }
+                } else if (valid) {
+                    hist_g[hrow(head, 0)] = pos.x; hist_g[hrow(head, 1)] = pos.y;
+                    hist_g[hrow(head, 2)] = vel.x; hist_g[hrow(head, 3)] = vel.y;
+                }
             }
             head = (head + 1 == CH) ? 0 : head + 1;
             // ... and the relative history moves on by one instant
@@ -251,9 +319,11 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
             r = (a == 0) ? r0 : r;
             r = r - T(2) * arena_bound<T>(t_abs<T>(pos.x));
             r = r - T(2) * arena_bound<T>(t_abs<T>(pos.y));
-            T total = lane_get<T>(r, w * CA);
+            rsum[tid] = r;
+            __syncthreads();        // (also: every thread has read the exchange area of this step)
+            T total = rsum[w_raw * CA];
 #pragma unroll
-            for (int i = 1; i < CA; ++i) total = total + lane_get<T>(r, w * CA + i);
+            for (int i = 1; i < CA; ++i) total = total + rsum[w_raw * CA + i];
             const T out = (MODE == 2) ? r : total;        // observe: what the callback returns
             if (MODE == 0 && au.step_count != nullptr) {
                 // ---- episode bookkeeping (mpe_step_auto): returns, step counter, time-limit reset ----
@@ -261,7 +331,7 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
                 const int cnt = au.step_count[b] + 1;
                 finished = cnt >= au.max_steps;
                 const int epi = au.episode_count[b] + 1;
-                // every lane of the world has read the counters before lane 0 of the world rewrites them
+                // every thread of the world has read the counters before its first thread rewrites them
                 __syncthreads();
                 if (valid) {
                     const T sum = ep[a] + total;
@@ -273,51 +343,83 @@ __global__ __launch_bounds__(64) void consensus_kernel(const ConsensusParams<T> 
                     }
                 }
                 // Scenario.reset_world with the next episode's draws for the worlds that finished; obs below is the fresh one
-                reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0}, finished);
+                reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0}, finished, 0);
             }
             if (valid) {
-                rew_g[row * CA + lane] = out;
+                rew_g[row * CA + tid] = out;        // 32 worlds x 6 rewards: six whole lines
                 // no done callback (environment.py:143-146); mpe_step_auto flags the step that reaches its time limit
-                if (MODE != 2 && a == 0) done_g[row + w] = finished ? 1 : 0;
+                if (MODE == 0 && a == 0) done_g[row + w] = finished ? 1 : 0;
+            }
+            if (MODE == 1 && (env0 & 127) == 0) {
+                // An episode launch has no time limit: done is 0 throughout.  A workgroup's 32 flags are a quarter of
+                // a 128-byte line: the workgroup that holds the first flag of a 128-flag block writes the whole block.
+                uint8_t* d = done_g + (long long)t * B + env0;
+                const long long n = B - env0 < 128 ? B - env0 : 128;
+                if ((((unsigned long long)(uintptr_t)d) & 3u) == 0 && n == 128) {
+                    if (tid < 32) reinterpret_cast<unsigned*>(d)[tid] = 0u;
+                } else if (tid < n) {
+                    d[tid] = 0;
+                }
             }
         }
 
-        // ---- observation(), consensus.py:122-140: the lane's 80 values into the image of the wave's rows ----
+        // ---- observation(), consensus.py:122-140: the lanes' 80 values into the image of the wave's rows ----
         {
             typedef T V4 __attribute__((ext_vector_type(4)));
-            V4* mine = reinterpret_cast<V4*>(tile + (w_raw * CA + a) * PAD);
-            if (lane < WPW * CA) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int k = 0; k < CH; k += 2) {
-                        V4 v;
-                        v[0] = R[g][k][0]; v[1] = R[g][k][1]; v[2] = R[g][k + 1][0]; v[3] = R[g][k + 1][1];
-                        mine[(g * CH + k) / 2] = v;
-                    }
-            }
-            __syncthreads();
-            T* const block = pre ? obs0_g + ((long long)(rs.period > 0 ? t / rs.period : 0) * B + env0) * ROW : obs_g + row * ROW;
-            // vector g of the wave's contiguous rows: values [VEC * g, + VEC) of agent-row g / NVA
-            constexpr int VEC = 16 / (int)sizeof(T), NV = WPW * ROW / VEC, NVR = ROW / VEC, NVA = COBS / VEC;
+            constexpr int VEC = 16 / (int)sizeof(T), NVA = COBS / VEC, NVT = TROWS * NVA;      // vectors per agent-row, per tile
             typedef T VT __attribute__((ext_vector_type(VEC)));
-            VT* dst = reinterpret_cast<VT*>(block);
-            const int nv = nvalid * NVR;
-#pragma unroll 4
-            for (int g = lane; g < NV; g += 64) {
-                const int ar = g / NVA, j = g - ar * NVA;
-                if (g < nv) dst[g] = *reinterpret_cast<const VT*>(tile + ar * PAD + j * VEC);
+            T* const my_tile = tiles[wave];
+            T* const block = pre ? obs0_g + ((long long)(rs.period > 0 ? t / rs.period : 0) * B + env0) * ROW : obs_g + row * ROW;
+            const int rows_valid = nvalid * CA;          // agent-rows of the workgroup that exist
+#pragma unroll 1
+            for (int half = 0; half < 64 / TROWS; ++half) {
+                if ((lane / TROWS) == half) {
+                    V4* mine = reinterpret_cast<V4*>(my_tile + (lane % TROWS) * PAD);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int k = 0; k < CH; k += 2) {
+                            V4 v;
+                            v[0] = R[g][k][0]; v[1] = R[g][k][1]; v[2] = R[g][k + 1][0]; v[3] = R[g][k + 1][1];
+                            mine[(g * CH + k) / 2] = v;
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // vector g of the tile's 32 contiguous agent-rows: values [VEC * j, + VEC) of agent-row g / NVA
+                const int row0 = wave * 64 + half * TROWS;
+                VT* dst = reinterpret_cast<VT*>(block + (long long)row0 * COBS);
+#pragma unroll 5
+                for (int i = 0; i < NVT / 64; ++i) {
+                    const int g = i * 64 + lane, ar = g / NVA, j = g - ar * NVA;
+                    if (row0 + ar < rows_valid) dst[g] = *reinterpret_cast<const VT*>(my_tile + ar * PAD + j * VEC);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            __syncthreads();
         }
         if (pre) pre = false;
         else ++t;
     }
 
-    if (MODE != 2 && valid) {
-        pos_g[(long long)(2 * a) * B + b] = pos.x; pos_g[(long long)(2 * a + 1) * B + b] = pos.y;
-        vel_g[(long long)(2 * a) * B + b] = vel.x; vel_g[(long long)(2 * a + 1) * B + b] = vel.y;
-        if (a == 0) aux_g[b] = head;
+    if (MODE != 2) {
+        if (same_heads) {
+            // The exchange area still holds what the last step (or reset) published, the final state as
+            // [agent][px, py, vx, vy] x 32 worlds: rows 2a, 2a+1 of pos and of vel, whole lines.
+#pragma unroll
+            for (int i = 0; i < CA * 4 * WPG / NT; ++i) {
+                const int j = i * NT + tid, r = j / WPG, wj = j - r * WPG, c = r & 3;
+                T* const dst = (c < 2) ? pos_g : vel_g;
+                if (wj < nvalid) dst[(long long)(2 * (r >> 2) + (c & 1)) * B + env0 + wj] = xch[r * XS + wj];
+            }
+            if (tid < nvalid) aux_g[env0 + tid] = head;
+        } else if (valid) {
+            pos_g[(long long)(2 * a) * B + b] = pos.x; pos_g[(long long)(2 * a + 1) * B + b] = pos.y;
+            vel_g[(long long)(2 * a) * B + b] = vel.x; vel_g[(long long)(2 * a + 1) * B + b] = vel.y;
+            if (a == 0) aux_g[b] = head;
+        }
     }
 }
 
@@ -357,7 +459,7 @@ ConsensusParams<T> make_consensus_params(const HostSpec& s, long long B) {
 template <typename T>
 hipError_t launch_consensus_t(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
     const auto p = make_consensus_params<T>(s, B);
-    const dim3 grid((unsigned)((B + WPW - 1) / WPW)), block(64);
+    const dim3 grid((unsigned)((B + WPG - 1) / WPG)), block(NT);
     T *pos = (T*)a.pos, *vel = (T*)a.vel, *hist = (T*)a.comm, *obs = (T*)a.obs, *rew = (T*)a.rew;
     if (mode == 0 && a.noise.enabled)
         hipLaunchKernelGGL((consensus_kernel<T, 0, true>), grid, block, 0, st, p, a.reset, a.au, a.noise, a.actions, pos, vel, hist, a.aux, obs, rew, a.done, (T*)nullptr, 1);

@@ -56,6 +56,14 @@ struct CfgBase {
     //   whole lines.  The world's state is staged in LDS (StagedRows); what observe_prepare returns and the aux words
     //   travel from the world's own lane by lane reads (ctx_from_lane).
     static constexpr bool OBS_COOP = false;
+    // stage_packed(): the cooperative passes' staging area without its padding word (row stride 2E + 2A, a multiple of 4
+    //   values), written as 16-byte vectors; for a scenario that needs the 256 bytes to fit eight workgroups a CU
+    template <typename T> __host__ __device__ static constexpr bool stage_packed() { return false; }
+    // Occupancy the compiler is to allow for in episode launches (waves per SIMD, i.e. a register budget of 512 / waves_per_simd()), and the
+    // action words a lane holds at once between a fetch and its packing in an episode launch (whole steps; more
+    // words mean fewer mid-launch fetches, each of which waits for the wave's older stores, but more registers)
+    template <typename T> __host__ __device__ static constexpr int waves_per_simd() { return 1; }
+    template <typename T> __host__ __device__ static constexpr int action_words() { return 84; }
     template <class Ctx> __device__ __forceinline__ static Ctx ctx_from_lane(const Ctx& c, int) { return c; }
     __host__ __device__ __forceinline__ static constexpr bool movable(int) { return true; }    // Agent.movable
     __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }    // not Agent.silent
@@ -88,22 +96,43 @@ struct Staged {
     }
 };
 
-// The same staging world-major: world (lane) l keeps its values at l * STRIDE + v, STRIDE odd, so that lanes reading
-// different values of ONE world (the cooperative observation passes) and lanes writing their own world are both
-// conflict-free.
-template <typename T, int E, int A>
+// The same staging world-major: world (lane) l keeps its values at l * STRIDE + v.  STRIDE is odd, so that lanes
+// reading different values of ONE world (the cooperative observation passes) and lanes writing their own world are
+// both conflict-free; PACKED drops the padding word when 2E + 2A is a multiple of the 16-byte vector and writes the
+// row as vectors (8 consecutive lanes' vectors of a 40-word stride fall on distinct banks; the passes' reads -- 8
+// worlds x at most 2 columns per instruction -- stay conflict-free except the agents' own positions, 2-way).
+template <typename T, int E, int A, bool PACKED = false>
 struct StagedRows {
-    static constexpr int STRIDE = (2 * E + 2 * A) | 1;
+    static constexpr int N = 2 * E + 2 * A, VEC = 16 / (int)sizeof(T);
+    static_assert(!PACKED || N % VEC == 0, "a packed row is a whole number of 16-byte vectors");
+    static constexpr int STRIDE = PACKED ? N : (N | 1);
     static constexpr int SIZE = STRIDE * 64;
     T* base;
     int lane;       // the world's column
     __device__ __forceinline__ V2<T> pos(int e) const { V2<T> v; v.x = base[lane * STRIDE + 2 * e]; v.y = base[lane * STRIDE + 2 * e + 1]; return v; }
     __device__ __forceinline__ V2<T> vel(int i) const { V2<T> v; v.x = base[lane * STRIDE + 2 * E + 2 * i]; v.y = base[lane * STRIDE + 2 * E + 2 * i + 1]; return v; }
     __device__ __forceinline__ void put(const V2<T> (&p)[E], const V2<T> (&w)[A]) const {
+        if constexpr (PACKED) {
+            typedef T VT __attribute__((ext_vector_type(VEC)));
+            T flat[N];
 #pragma unroll
-        for (int e = 0; e < E; ++e) { base[lane * STRIDE + 2 * e] = p[e].x; base[lane * STRIDE + 2 * e + 1] = p[e].y; }
+            for (int e = 0; e < E; ++e) { flat[2 * e] = p[e].x; flat[2 * e + 1] = p[e].y; }
 #pragma unroll
-        for (int i = 0; i < A; ++i) { base[lane * STRIDE + 2 * E + 2 * i] = w[i].x; base[lane * STRIDE + 2 * E + 2 * i + 1] = w[i].y; }
+            for (int i = 0; i < A; ++i) { flat[2 * E + 2 * i] = w[i].x; flat[2 * E + 2 * i + 1] = w[i].y; }
+            VT* row = reinterpret_cast<VT*>(base + lane * STRIDE);
+#pragma unroll
+            for (int q = 0; q < N / VEC; ++q) {
+                VT v;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[k] = flat[q * VEC + k];
+                row[q] = v;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { base[lane * STRIDE + 2 * e] = p[e].x; base[lane * STRIDE + 2 * e + 1] = p[e].y; }
+#pragma unroll
+            for (int i = 0; i < A; ++i) { base[lane * STRIDE + 2 * E + 2 * i] = w[i].x; base[lane * STRIDE + 2 * E + 2 * i + 1] = w[i].y; }
+        }
     }
 };
 
@@ -774,6 +803,13 @@ struct PredatorPreyCfg : CfgBase {
     // a 64 x 315 tile (80 KB in float32) would leave one wave per CU: 8 whole rows at a time, the lanes regrouped
     // as 8 worlds x 7 agents (8 lanes idle during the observation)
     static constexpr bool OBS_COOP = true;
+    // Two waves per SIMD (all 2 048 waves of a 131 072-world launch resident at once): 256 registers, eight 20 KB
+    // workgroups a CU.  The kernel fits the registers with 6 steps' action words per fetch; what still spills does so
+    // around the fetch and the reset draws, outside the steps.
+    // (float32; the float64 build keeps one wave per SIMD)
+    template <typename T> __host__ __device__ static constexpr bool stage_packed() { return sizeof(T) == 4; }
+    template <typename T> __host__ __device__ static constexpr int waves_per_simd() { return sizeof(T) == 4 ? 2 : 1; }
+    template <typename T> __host__ __device__ static constexpr int action_words() { return sizeof(T) == 4 ? 42 : 84; }
     __host__ __device__ __forceinline__ static constexpr int chunk_width(int) { return OBS_DIM; }
     __host__ __device__ __forceinline__ static constexpr int chunk_offset(int c) { return c * OBS_DIM; }
 

@@ -6,10 +6,3 @@ hipError_t launch_small_f32_core(const HostSpec& s, long long B, int mode, const
     return launch_small_group<float, GROUP_CORE>(s, B, mode, a, st);
 }
 }  // namespace mpe
-
-#ifdef MPE_STAMPS
-// Diagnostic build only: copy the per-workgroup timestamps to host memory.
-extern "C" int mpe_debug_stamps(long long* host, long long count) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mpe::g_stamps), (size_t)count * sizeof(long long));
-}
-#endif

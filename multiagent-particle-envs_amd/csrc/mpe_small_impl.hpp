@@ -84,9 +84,6 @@ struct Tile {
 // block at gbase (row stride OT).  The tile's row stride is the widest chunk, made odd when that
 // width would put every lane's row on the same few LDS banks; chunks of such a tile whose width is
 // a whole number of 16-byte vectors leave as vectors, the others 4 bytes per lane.
-#ifndef MPE_ACTION_WORDS
-#define MPE_ACTION_WORDS 84      // action words a lane holds at once between a fetch and its packing
-#endif
 template <typename T, class Cfg>
 struct ChunkTile {
     static constexpr bool LINEAR = ((Cfg::CHUNK_MAX * (int)sizeof(T) / 4) % 16) != 0;
@@ -133,11 +130,21 @@ struct ObsChunks {
 
 #ifdef MPE_STAMPS
 // Diagnostic build only: 100 MHz timestamps per workgroup (slot 0 start, 1 state and actions ready,
-// 2+t step t computed and its rows issued, 60 all steps done).  tools/probes/episode_stamps.py reads them.
+// 2+t step t computed and its rows issued, 60 all steps done; within step 10: 30 physics done, 31 rewards
+// done, 32 state staged, 33.. cooperative pass k flushed, 41 post_step done).  tools/probes/episode_stamps.py
+// and tools/probes/step_phases.py read them.
 __device__ long long g_stamps[4096 * 64];
+}  // namespace mpe
+// copies the timestamps to host memory; the one translation unit built with -DMPE_STAMPS defines it
+extern "C" int mpe_debug_stamps(long long* host, long long count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mpe::g_stamps), (size_t)count * sizeof(long long));
+}
+namespace mpe {
 #define STAMP(slot) do { if (lane == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_T(slot) do { if (t == 10) STAMP(slot); } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define STAMP_T(slot) do { } while (0)
 #endif
 
 // EPW: envs per wave (tile rows); 64 uses every lane.
@@ -148,7 +155,7 @@ __device__ long long g_stamps[4096 * 64];
 // NOISE: the world has agents with u_noise / c_noise (its own instantiation: the generator is an out-of-line
 //   call, and a kernel with a call site pays for the calling convention in registers on every path).
 template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false>
-__global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs, const AutoArgs au,
+__global__ __launch_bounds__(64, MODE == MODE_ROLLOUT ? Cfg::template waves_per_simd<T>() : 1) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs, const AutoArgs au,
                                                    const long long env_begin, const long long env_end,
                                                    const int* __restrict__ actions, T* __restrict__ pos_g,
                                                    T* __restrict__ vel_g, T* __restrict__ comm_g,
@@ -167,14 +174,22 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     static_assert(!COOP || (EPW == 64 && A <= 8 && !Cfg::OBS_LOOP && RP == 0), "cooperative passes regroup a full wave as 8 worlds x up to 8 agents");
     constexpr int TROWS = COOP ? 8 : (RP > 0 ? EPW / RP : EPW);
     using ObsTile = Tile<T, (COOP ? OT : OW), (COOP ? true : LIN), TROWS>;
+    using CoopStage = StagedRows<T, E, A, Cfg::template stage_packed<T>()>;
     using RewTile = Tile<T, A, true, EPW>;
     using IiTile = Tile<int, NI, true, EPW>;
     using IfTile = Tile<T, NF, true, EPW>;
     __shared__ __attribute__((aligned(16))) T tile_obs[ObsTile::SIZE];
-    __shared__ __attribute__((aligned(16))) T tile_rew[RewTile::SIZE];
-    __shared__ T stage_lds[Cfg::OBS_LOOP ? Staged<T, E, A>::SIZE : (COOP ? StagedRows<T, E, A>::SIZE : 1)];
-    __shared__ __attribute__((aligned(16))) int tile_ii[INFO ? IiTile::SIZE : 4];
-    __shared__ __attribute__((aligned(16))) T tile_if[INFO ? IfTile::SIZE : 4];
+    __shared__ __attribute__((aligned(16))) T stage_lds[Cfg::OBS_LOOP ? Staged<T, E, A>::SIZE : (COOP ? CoopStage::SIZE : 1)];
+    // Under cooperative passes the reward and info tiles live in the observation tile: they leave right after the
+    // rewards are known, before the first pass writes rows there (20 KB of LDS a workgroup: eight fit a CU).
+    constexpr int REW_BYTES = (RewTile::SIZE * (int)sizeof(T) + 15) / 16 * 16, II_BYTES = INFO ? (IiTile::SIZE * 4 + 15) / 16 * 16 : 0;
+    static_assert(!COOP || REW_BYTES + II_BYTES + (INFO ? IfTile::SIZE : 0) * (int)sizeof(T) <= ObsTile::SIZE * (int)sizeof(T), "small tiles must fit the observation tile");
+    __shared__ __attribute__((aligned(16))) T tile_rew_own[COOP ? 4 : RewTile::SIZE];
+    __shared__ __attribute__((aligned(16))) int tile_ii_own[INFO && !COOP ? IiTile::SIZE : 4];
+    __shared__ __attribute__((aligned(16))) T tile_if_own[INFO && !COOP ? IfTile::SIZE : 4];
+    T* const tile_rew = COOP ? tile_obs : tile_rew_own;
+    int* const tile_ii = COOP ? reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(tile_obs) + REW_BYTES) : tile_ii_own;
+    T* const tile_if = COOP ? reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(tile_obs) + REW_BYTES + II_BYTES) : tile_if_own;
 
     const int lane = threadIdx.x;
     const long long B = p.n_envs;
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
     constexpr int BITS = Cfg::BITS, ABITS = BITS * NA;
     constexpr unsigned AMASK = (1u << BITS) - 1u;
     constexpr int CH = (MODE == MODE_ROLLOUT) ? (128 / ABITS) : 1;
-    constexpr int NP_EPISODE = (25 + CH - 1) / CH, NP_BUDGET = MPE_ACTION_WORDS / (CH * NA) > 0 ? MPE_ACTION_WORDS / (CH * NA) : 1;
+    constexpr int NP_EPISODE = (25 + CH - 1) / CH, NP_BUDGET = Cfg::template action_words<T>() / (CH * NA) > 0 ? Cfg::template action_words<T>() / (CH * NA) : 1;
     constexpr int NP = (MODE == MODE_ROLLOUT) ? (NP_EPISODE < NP_BUDGET ? NP_EPISODE : NP_BUDGET) : 1;
     static_assert(ABITS <= 64, "one step's actions must fit 64 bits");
     unsigned __int128 fetched[NP] = {};
@@ -445,6 +460,7 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
                 if (Cfg::movable(i)) integrate<T, CLAMP>(pos[i], vel[i], force[i], p.mass[Cfg::rep(i)], p.max_speed[Cfg::rep(i)], p.one_minus_damping, p.dt);
         }
 
+        STAMP_T(30);
         // ---- scenario callbacks into the wave's LDS tiles ----
         const bool want_score = !pre && ((MODE != MODE_OBSERVE) || (rew_g != nullptr));   // observe: rewards on request
         bool finished = false;
@@ -506,8 +522,43 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             }
             if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
         }
+        STAMP_T(31);
         const long long row0 = (long long)t * B + env0;
         T* const obs_dst = pre ? obs0_g + (ep_idx * B + env0) * OT : obs_g + row0 * OT;
+        auto flush_small = [&]() {
+            // (a kernel on a tight register budget: an opaque copy of the lane keeps the flushes' addresses per-step
+            // work; hoisted out of the step loop they are spilled, and every reload waits for the wave's older stores)
+            int lane_f = lane;
+            if constexpr (MODE == MODE_ROLLOUT && Cfg::template waves_per_simd<T>() > 1) asm volatile("" : "+v"(lane_f));
+            if (want_score) {
+                RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane_f, nvalid);
+                if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
+                    // No scenario ends an episode (environment.py:143-146) and a rollout has no time limit, so
+                    // done is 0 throughout.  A wave's 64 flags are half a 128-byte line: neighbouring waves take
+                    // turns (even steps the even wave, odd steps the odd one) to write both halves as one
+                    // full line; a last wave without a neighbour writes its own half.
+                    const long long pair0 = env_begin + (long long)(blockIdx.x & ~1u) * 64;
+                    const bool paired = pair0 + 128 <= env_end;
+                    if (paired) {
+                        if (((unsigned)t & 1u) == (blockIdx.x & 1u) && lane_f < 32)
+                            reinterpret_cast<unsigned*>(done_g + (long long)t * B + pair0)[lane_f] = 0u;
+                    } else {
+                        done_g[row0 + lane_f] = 0;
+                    }
+                } else if (MODE != MODE_OBSERVE && valid) {
+                    done_g[row0 + lane_f] = finished ? 1 : 0;
+                }
+                if (want_info) {
+                    IiTile::template flush<FULL>(tile_ii, info_i_g + row0 * NI, lane_f, nvalid);
+                    if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::template flush<FULL>(tile_if, info_f_g + row0 * NF, lane_f, nvalid);
+                }
+            }
+        };
+        if constexpr (COOP) {
+            __syncthreads();
+            flush_small();
+            __syncthreads();    // the passes below write their rows over these tiles
+        }
         if constexpr (Cfg::OBS_LOOP) {
             // one copy of the per-agent observation code, looped over the agents; every lane reads back only
             // the column of the staging area it wrote itself, so no barrier is needed before the first read
@@ -546,10 +597,11 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
             // whose int state and per-step context it fetches from that world's lane (lanes beyond 8 * A idle).  One
             // observe_agent per lane and pass: the same arithmetic as a loop over the agents, but the tile is a byte
             // image of 8 consecutive rows and leaves as 16-byte vectors, whole 128-byte lines.
-            const StagedRows<T, E, A> own{stage_lds, lane};
+            const CoopStage own{stage_lds, lane};
             own.put(pos, vel);
             const auto ctx = Cfg::template observe_prepare<T>(pos, p);
             __syncthreads();
+            STAMP_T(32);
             const int k_in = lane % TROWS, ag = lane / TROWS;
 #pragma unroll 1
             for (int pass = 0; pass < 64 / TROWS; ++pass) {
@@ -558,13 +610,14 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
 #pragma unroll
                 for (int k = 0; k < NX; ++k) auxw[k] = __shfl(aux[k], wl, 64);
                 const auto ctxw = Cfg::ctx_from_lane(ctx, wl);
-                const StagedRows<T, E, A> theirs{stage_lds, wl};
+                const CoopStage theirs{stage_lds, wl};
                 if (A == 8 || ag < A) Cfg::template observe_agent<T>(ag, theirs, auxw, ctxw, tile_obs + k_in * OT + Cfg::chunk_offset(ag));
                 __syncthreads();
                 int nv = nvalid - pass * TROWS;
                 nv = nv < 0 ? 0 : (nv > TROWS ? TROWS : nv);
                 ObsTile::template flush<FULL>(tile_obs, obs_dst + (long long)(pass * TROWS) * OT, lane, nv);
                 __syncthreads();
+                STAMP_T(33 + pass);
             }
         } else if constexpr (RP > 0) {
             // Whole rows, TROWS worlds at a time: every lane evaluates the observation in each pass, the lanes of
@@ -597,30 +650,9 @@ __global__ __launch_bounds__(64) void small_kernel(const SmallParams<T, Cfg::E, 
         // reset starts its episode untouched
         if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, (unsigned long long)b);
         __syncthreads();
+        STAMP_T(41);
         if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) ObsTile::template flush<FULL>(tile_obs, obs_dst, lane, nvalid);
-        if (want_score) {
-            RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane, nvalid);
-            if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
-                // No scenario ends an episode (environment.py:143-146) and a rollout has no time limit, so
-                // done is 0 throughout.  A wave's 64 flags are half a 128-byte line: neighbouring waves take
-                // turns (even steps the even wave, odd steps the odd one) to write both halves as one
-                // full line; a last wave without a neighbour writes its own half.
-                const long long pair0 = env_begin + (long long)(blockIdx.x & ~1u) * 64;
-                const bool paired = pair0 + 128 <= env_end;
-                if (paired) {
-                    if (((unsigned)t & 1u) == (blockIdx.x & 1u) && lane < 32)
-                        reinterpret_cast<unsigned*>(done_g + (long long)t * B + pair0)[lane] = 0u;
-                } else {
-                    done_g[row0 + lane] = 0;
-                }
-            } else if (MODE != MODE_OBSERVE && valid) {
-                done_g[row0 + lane] = finished ? 1 : 0;
-            }
-            if (want_info) {
-                IiTile::template flush<FULL>(tile_ii, info_i_g + row0 * NI, lane, nvalid);
-                if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::template flush<FULL>(tile_if, info_f_g + row0 * NF, lane, nvalid);
-            }
-        }
+        if constexpr (!COOP) flush_small();
         if (MODE == MODE_ROLLOUT) {
             if (t >= 0 && t < 28) STAMP(2 + t);
             __syncthreads();   // tiles are rewritten by the next step

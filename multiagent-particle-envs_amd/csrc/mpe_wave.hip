@@ -321,11 +321,22 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                         if (info_f_g) info_f_g[row * (A + 1) + 1 + lane] = bench;
                     }
                     if (lane == 0) {
-                        if (MODE != WMODE_OBSERVE) done_g[row] = 0;
                         if (want_info) {
                             info_i_g[row * (A + 1) + A] = occupied;
                             if (info_f_g) info_f_g[row * (A + 1)] = min_dists;
                         }
+                    }
+                }
+                // No scenario ends an episode (environment.py:143-146): done is 0 unless mpe_step_auto's time limit
+                // sets it (below).  A world's flag is one byte of a 128-byte line, so the world that holds the first
+                // flag of a 128-flag block writes the whole block.
+                if (MODE != WMODE_OBSERVE && au.step_count == nullptr && (b & 127) == 0) {
+                    uint8_t* d = done_g + row;
+                    const long long n = B - b < 128 ? B - b : 128;
+                    if ((((unsigned long long)(uintptr_t)d) & 3u) == 0 && n == 128) {
+                        if (lane < 32) reinterpret_cast<unsigned*>(d)[lane] = 0u;
+                    } else if (lane < n) {
+                        d[lane] = 0;
                     }
                 }
                 __syncthreads();        // mind_s is rewritten by the next step; P may be reset below
