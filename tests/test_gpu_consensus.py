@@ -134,6 +134,37 @@ def test_large_batch_fp64_against_oracle_with_masked_reset():
     assert len(set(env.aux[0].cpu().numpy().tolist())) == 2
 
 
+@pytest.mark.parametrize("n_masked", [40, 7])
+@pytest.mark.parametrize("T", [4, 13, 25])
+def test_rollout_after_a_partial_reset_equals_stepping(n_masked, T):
+    """Some workgroups' worlds agree on their ring head, one holds both kinds: the whole-line and the per-thread
+    form of the ring read, the slot stores (only the slots the launch does not overwrite) and the state
+    write-back must leave the same state as single steps, ring included."""
+    B = 200
+    e1, e2 = _env(B, torch.float32), _env(B, torch.float32)
+    gen = torch.Generator("cuda:0").manual_seed(8)
+    for e in (e1, e2):
+        e.reset(seed=3, observe=False)
+    for t in range(3):
+        a = torch.randint(0, 5, (B, 6), dtype=torch.int32, device="cuda:0", generator=gen)
+        e1.step(a)
+        e2.step(a)
+    mask = torch.zeros(B, dtype=torch.uint8)
+    mask[:n_masked] = 1
+    for e in (e1, e2):
+        e.reset(seed=4, mask=mask, observe=False)
+    assert len(set(e1.aux[0].cpu().numpy().tolist())) == 2
+    a = torch.randint(0, 5, (T, B, 6), dtype=torch.int32, device="cuda:0", generator=gen)
+    out = e2.rollout(a)
+    for t in range(T):
+        obs, rew, done, _ = e1.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t]) and torch.equal(done, out["done"][t]), t
+    for k in ("pos", "vel", "aux"):
+        assert torch.equal(getattr(e1, k), getattr(e2, k)), k
+    h1, h2 = e1.get_history(), e2.get_history()
+    assert np.array_equal(h1[0], h2[0]) and np.array_equal(h1[1], h2[1])
+
+
 def test_drop_in_env_replays_the_reference():
     import mpe_hip
     g = load_golden(CASE)
