@@ -64,3 +64,14 @@ def test_specs_match_oracle_specs():
                      (p.adversary, o.adversary), (p.leader, o.leader)):
             assert np.array_equal(np.asarray(a), np.asarray(b))
         assert (p.dt, p.damping, p.contact_force, p.contact_margin) == (o.dt, o.damping, o.contact_force, o.contact_margin)
+
+
+def test_library_was_built_from_these_sources():
+    """build() notes the hash of the kernel sources next to the library; a library left over from other sources
+    would make every GPU test check the wrong code."""
+    import bench
+    from mpe_hip import _lib
+    note = _lib.LIB_PATH + ".sources"
+    if not os.path.exists(note):
+        pytest.skip("library not built by __graft_entry__.build()")
+    assert open(note).read().strip() == bench.source_hash(), "run `python __graft_entry__.py build`"
