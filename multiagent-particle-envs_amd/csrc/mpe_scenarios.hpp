@@ -319,12 +319,16 @@ struct WorldCommCfg : CfgBase {
         return (i1 && o1) || (i2 && o2) || (!i1 && !o1 && !i2 && !o2) || leader(i);
     }
 
-    // The 192-value row leaves in two halves of 96 columns (three full 128-byte lines of a float32 row each)
-    // through a tile of half the size: a 64 x 193 float32 tile is 49 KB of LDS, which leaves room for three
-    // of these one-wave workgroups per CU, one short of its four SIMDs.
-    static constexpr int OBS_CHUNKS = 2, CHUNK_MAX = OBS_TOTAL / 2, CHUNK_MIN = OBS_TOTAL / 2;
-    __host__ __device__ __forceinline__ static constexpr int chunk_width(int) { return OBS_TOTAL / 2; }
-    __host__ __device__ __forceinline__ static constexpr int chunk_offset(int c) { return c * (OBS_TOTAL / 2); }
+    // The 192-value row leaves in three chunks of 64 columns (two full 128-byte lines of a float32 row each)
+    // through a tile of a third of the size: a 64 x 193 float32 tile is 49 KB of LDS, room for three of these
+    // one-wave workgroups per CU; two halves (25 KB) for six; a third (16.6 KB, 18 KB with the reward tile) for the
+    // eight that two waves per SIMD need.  The episode kernel fits 256 registers with 6 steps' action words per fetch
+    // (2 registers spilled) and runs two rounds of 2 048 resident waves at 262 144 worlds instead of four of 1 024.
+    static constexpr int OBS_CHUNKS = 3, CHUNK_MAX = OBS_TOTAL / OBS_CHUNKS, CHUNK_MIN = OBS_TOTAL / OBS_CHUNKS;
+    __host__ __device__ __forceinline__ static constexpr int chunk_width(int) { return OBS_TOTAL / OBS_CHUNKS; }
+    __host__ __device__ __forceinline__ static constexpr int chunk_offset(int c) { return c * (OBS_TOTAL / OBS_CHUNKS); }
+    template <typename T> __host__ __device__ static constexpr int waves_per_simd() { return sizeof(T) == 4 ? 2 : 1; }
+    template <typename T> __host__ __device__ static constexpr int action_words() { return sizeof(T) == 4 ? 42 : 84; }
     __host__ __device__ __forceinline__ static constexpr int obs_offset(int i) { return i < N_ADV ? i * OBS_ADV : N_ADV * OBS_ADV + (i - N_ADV) * OBS_GOOD; }
 
     // in_forest bits of every agent (bit 2i+f), shared by the chunks of one step's observation
@@ -393,7 +397,7 @@ struct WorldCommCfg : CfgBase {
 
     template <typename T, int C>
     __device__ static __forceinline__ void observe_chunk(const V2<T> (&pos)[E], const V2<T> (&vel)[A], const T* comm, const int*, int forest, T* row) {
-        observe_cols<T, C * (OBS_TOTAL / 2), (C + 1) * (OBS_TOTAL / 2)>(pos, vel, comm, forest, row);
+        observe_cols<T, C * (OBS_TOTAL / OBS_CHUNKS), (C + 1) * (OBS_TOTAL / OBS_CHUNKS)>(pos, vel, comm, forest, row);
     }
 
     template <typename T, class P>
