@@ -14,6 +14,7 @@
 //  16-19  as 0 with 2 / 4 / 8 / 16 stores per thread (interleaved over the workgroup) before the workgroup ends
 //  20-27  persistent waves that write only the 4 KB blocks with index (XCD + C) mod 8, C = 0..7
 //  28-30  as 0 with workgroups of 128 / 512 / 1024 threads        31  as 0, each thread a second store half the buffer away
+//  32  as 3 with 8-byte stores      33 / 34  two-wave workgroups writing 64 KB per plane with 8- / 16-byte stores (a wave-per-world launch)
 // hipcc --offload-arch=gfx950 -O3 -o fill_shapes fill_shapes.hip && ./fill_shapes [GiB]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -127,18 +128,41 @@ __global__ __launch_bounds__(256) void v31(float4* p, size_t half) {
     q[half] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
+// as 3 with 8-byte stores (twice the instructions, 512 bytes = four lines per wave and instruction)
+__global__ __launch_bounds__(64) void v32(float2* p, size_t plane_vecs) {
+    float2 v = make_float2(1.f, 2.f);
+    for (int t = 0; t < T; ++t) {
+        float2* q = p + (size_t)t * plane_vecs + (size_t)blockIdx.x * (CH * 128) + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 2 * CH; ++i) q[i * 64] = v;
+        v.x += 1.f;
+    }
+}
+// a wave-per-world launch's shape: two-wave workgroups, each living T planes and writing 66 KB per plane, the two
+// waves interleaved; VB = bytes per lane and store
+template <typename V>
+__global__ __launch_bounds__(128) void v33(V* p, size_t plane_vecs, int vecs_per_wg) {
+    V v{};
+    for (int t = 0; t < T; ++t) {
+        V* q = p + (size_t)t * plane_vecs + (size_t)blockIdx.x * vecs_per_wg + threadIdx.x;
+#pragma unroll 4
+        for (int i = 0; i < vecs_per_wg; i += 128) q[i] = v;
+    }
+}
+
 int main(int argc, char** argv) {
     const double gib = argc > 1 ? atof(argv[1]) : 4.0;
     // waves of the persistent variants: a whole number of (T * CH KB) regions
     const size_t waves = (size_t)(gib * 1073741824.0 / (T * CH * 1024.0));
     const size_t n_bytes = waves * T * CH * 1024, n_vecs = n_bytes / 16;
     const unsigned w20 = (unsigned)((n_bytes / (T * 3 * 4096)) & ~(size_t)7);       // waves of variants 20-27
+    const unsigned wg33 = (unsigned)(n_bytes / ((size_t)T * 65536));        // workgroups of variants 33-34 (64 KB per plane each)
     float4* p;
     CK(hipMalloc(&p, n_bytes));
     CK(hipMemset(p, 0, n_bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf("%.2f GiB, %zu waves in the persistent variants\n", n_bytes / 1073741824.0, waves);
-    for (int variant = 0; variant < 32; ++variant) {
+    for (int variant = 0; variant < 35; ++variant) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; ++rep) {
             CK(hipEventRecord(e0));
@@ -174,13 +198,16 @@ int main(int argc, char** argv) {
                 case 29: hipLaunchKernelGGL(v28<512>, dim3((unsigned)(n_vecs / 512)), dim3(512), 0, 0, p); break;
                 case 30: hipLaunchKernelGGL(v28<1024>, dim3((unsigned)(n_vecs / 1024)), dim3(1024), 0, 0, p); break;
                 case 31: hipLaunchKernelGGL(v31, dim3((unsigned)(n_vecs / 512)), dim3(256), 0, 0, p, n_vecs / 2); break;
+                case 32: hipLaunchKernelGGL(v32, dim3((unsigned)waves), dim3(64), 0, 0, (float2*)p, n_vecs * 2 / T); break;
+                case 33: hipLaunchKernelGGL(v33<float2>, dim3(wg33), dim3(128), 0, 0, (float2*)p, (size_t)wg33 * 8192, 8192); break;
+                case 34: hipLaunchKernelGGL(v33<float4>, dim3(wg33), dim3(128), 0, 0, p, (size_t)wg33 * 4096, 4096); break;
                 case 6: hipLaunchKernelGGL(v3<1>, dim3((unsigned)(waves & ~(size_t)7)), dim3(64), 0, 0, p, n_vecs / T); break;
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep > 0 && ms < best) best = ms;
         }
-        const double bytes = variant >= 20 ? (double)w20 * T * 3 * 4096 : (double)n_bytes;
+        const double bytes = variant >= 33 ? (double)wg33 * T * 65536 : (variant >= 20 && variant < 28 ? (double)w20 * T * 3 * 4096 : (double)n_bytes);
         printf("variant %d  %.3f ms  %.0f GB/s\n", variant, best, bytes / (best * 1e-3) / 1e9);
     }
     return 0;
