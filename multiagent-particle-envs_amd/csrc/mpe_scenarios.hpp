@@ -59,9 +59,11 @@ struct CfgBase {
     // stage_packed(): the cooperative passes' staging area without its padding word (row stride 2E + 2A, a multiple of 4
     //   values), written as 16-byte vectors; for a scenario that needs the 256 bytes to fit eight workgroups a CU
     template <typename T> __host__ __device__ static constexpr bool stage_packed() { return false; }
-    // Occupancy the compiler is to allow for in episode launches (waves per SIMD, i.e. a register budget of 512 / waves_per_simd()), and the
-    // action words a lane holds at once between a fetch and its packing in an episode launch (whole steps; more
-    // words mean fewer mid-launch fetches, each of which waits for the wave's older stores, but more registers)
+    // Occupancy the compiler is to allow for in episode launches of full tiles (waves per SIMD, i.e. a register budget
+    // of 512 / waves_per_simd(); the guarded instantiations for ragged tails, odd batch sizes and noise, and those with
+    // benchmark outputs, keep the whole register file: held to half of it they spill inside the steps), and the
+    // action words a lane holds at once between a fetch and its packing in an episode launch (whole steps; more words
+    // mean fewer mid-launch fetches, each of which waits for the wave's older stores, but more registers)
     template <typename T> __host__ __device__ static constexpr int waves_per_simd() { return 1; }
     template <typename T> __host__ __device__ static constexpr int action_words() { return 84; }
     template <class Ctx> __device__ __forceinline__ static Ctx ctx_from_lane(const Ctx& c, int) { return c; }
@@ -226,6 +228,9 @@ struct TagCfg : CfgBase {
     static constexpr int OBS_TOTAL = N_ADV * OBS_ADV + (A - N_ADV) * OBS_GOOD;
     static constexpr int NI = A, NF = 0, N_AUX = 0;
     __host__ __device__ __forceinline__ static constexpr bool collides(int) { return true; }   // simple_tag.py:19,30
+    // a 25-step episode's 100 action words in one fetch (three shift registers): no refill in mid-launch
+    template <typename T> __host__ __device__ static constexpr int action_words() { return 120; }
+    template <typename T> __host__ __device__ static constexpr int waves_per_simd() { return sizeof(T) == 4 ? 2 : 1; }
     __host__ __device__ __forceinline__ static constexpr bool speaks(int) { return false; }
     __host__ __device__ __forceinline__ static constexpr bool adversary(int i) { return i < N_ADV; }
 
@@ -681,6 +686,8 @@ struct ReferenceCfg : CfgBase {
     static constexpr int A = 2, L = 3, E = 5;
     static constexpr int DIM_C = 10, S = 2, N_ACT = 4;      // [move 0, word 0, move 1, word 1]
     static constexpr int BITS = 4;
+    // a 25-step episode's 100 action words in one fetch (four shift registers of 8 steps): no refill in mid-launch
+    template <typename T> __host__ __device__ static constexpr int action_words() { return 128; }
     static constexpr int OBS_DIM = 2 + 2 * L + 3 + DIM_C, OBS_TOTAL = A * OBS_DIM;
     static constexpr int NI = 2, NF = A, N_AUX = 2;
     static constexpr bool SHARED = true;                     // :10

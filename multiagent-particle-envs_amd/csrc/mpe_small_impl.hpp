@@ -155,7 +155,7 @@ namespace mpe {
 // NOISE: the world has agents with u_noise / c_noise (its own instantiation: the generator is an out-of-line
 //   call, and a kernel with a call site pays for the calling convention in registers on every path).
 template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false>
-__global__ __launch_bounds__(64, MODE == MODE_ROLLOUT ? Cfg::template waves_per_simd<T>() : 1) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs, const AutoArgs au,
+__global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOISE) ? Cfg::template waves_per_simd<T>() : 1) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs, const AutoArgs au,
                                                    const long long env_begin, const long long env_end,
                                                    const int* __restrict__ actions, T* __restrict__ pos_g,
                                                    T* __restrict__ vel_g, T* __restrict__ comm_g,
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64, MODE == MODE_ROLLOUT ? Cfg::template waves_per_
             // (a kernel on a tight register budget: an opaque copy of the lane keeps the flushes' addresses per-step
             // work; hoisted out of the step loop they are spilled, and every reload waits for the wave's older stores)
             int lane_f = lane;
-            if constexpr (MODE == MODE_ROLLOUT && Cfg::template waves_per_simd<T>() > 1) asm volatile("" : "+v"(lane_f));
+            if constexpr (MODE == MODE_ROLLOUT && FULL && !INFO && !NOISE && Cfg::template waves_per_simd<T>() > 1) asm volatile("" : "+v"(lane_f));
             if (want_score) {
                 RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane_f, nvalid);
                 if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
