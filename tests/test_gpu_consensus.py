@@ -165,6 +165,26 @@ def test_rollout_after_a_partial_reset_equals_stepping(n_masked, T):
     assert np.array_equal(h1[0], h2[0]) and np.array_equal(h1[1], h2[1])
 
 
+@pytest.mark.parametrize("B", [1, 5, 31, 32, 33, 64, 97, 127, 128, 129, 132, 260])
+def test_ragged_batches_rollout_equals_stepping(B):
+    """Workgroups of 32 worlds with fewer than 32 valid ones, batches that are no multiple of 4 (byte-wise done
+    flags) and blocks of 128 done flags cut short: an episode launch (with its reset observation) against
+    mpe_reset + single steps."""
+    T = 12
+    e1, e2 = _env(B, torch.float32), _env(B, torch.float32)
+    a = torch.randint(0, 5, (T, B, 6), dtype=torch.int32, device="cuda:0", generator=torch.Generator("cuda:0").manual_seed(B))
+    obs0 = e1.reset(seed=9)
+    out = e2.rollout(a, reset_seed=9, obs0=True)
+    assert torch.equal(out["obs0"].reshape(obs0.shape), obs0)
+    for t in range(T):
+        obs, rew, done, _ = e1.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t]) and torch.equal(done, out["done"][t]), t
+    for k in ("pos", "vel", "aux"):
+        assert torch.equal(getattr(e1, k), getattr(e2, k)), k
+    h1, h2 = e1.get_history(), e2.get_history()
+    assert np.array_equal(h1[0], h2[0]) and np.array_equal(h1[1], h2[1])
+
+
 def test_drop_in_env_replays_the_reference():
     import mpe_hip
     g = load_golden(CASE)

@@ -273,3 +273,20 @@ def test_plugin_env_with_post_step_replays_the_reference(fused):
         assert info["n"] == list(g["collisions"][t, b])
         assert [m.holding for m in world.agents[4:]] == list(g["holding"][t, b])
     assert g["holding0"][b].any() and not g["holding"][-1, b].any()
+
+
+@pytest.mark.parametrize("B", [1, 3, 64, 65, 128, 130, 132, 200])
+def test_ragged_batches_rollout_equals_stepping(B):
+    """Full tiles (the two-waves-per-SIMD instantiation), ragged tails and batches that are no multiple of 4 (every
+    wave guarded) in one sweep: an episode launch with its reset observation against mpe_reset + single steps."""
+    T = 9
+    e1, e2 = _env(B, torch.float32, info=False), _env(B, torch.float32, info=False)
+    a = torch.randint(0, 5, (T, B, 7), dtype=torch.int32, device="cuda:0", generator=torch.Generator("cuda:0").manual_seed(B))
+    obs0 = e1.reset(seed=9)
+    out = e2.rollout(a, reset_seed=9, obs0=True)
+    assert torch.equal(out["obs0"].reshape(obs0.shape), obs0)
+    for t in range(T):
+        obs, rew, done, _ = e1.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t]) and torch.equal(done, out["done"][t]), t
+    for k in ("pos", "vel", "aux"):
+        assert torch.equal(getattr(e1, k), getattr(e2, k)), k
