@@ -42,7 +42,6 @@ constexpr int WPG = 32;          // worlds per workgroup
 constexpr int NT = WPG * CA;     // its threads: thread = world * 6 + agent, three full waves
 constexpr int XS = WPG + 1;      // row stride of the exchange area (odd: a wave's writes spread over the banks)
 constexpr int ROW = CA * COBS;   // observation values of one world-step
-constexpr int TROWS = 32;        // agent-rows a wave's tile holds (half of its 64 lanes' rows)
 
 // MODE 0: mpe_step / mpe_step_auto, 1: mpe_rollout / mpe_episode(s), 2: mpe_observe
 // NOISE: agents with u_noise (its own instantiation: the generator is an out-of-line call)
@@ -56,7 +55,8 @@ constexpr int TROWS = 32;        // agent-rows a wave's tile holds (half of its 
 // so they exchange their fresh position and velocity (and their reward terms) through LDS.  The history ring in
 // device memory (the form the state has between launches) is read once at the start of a launch; a step stores
 // its slot only if no later step of the launch overwrites it.  Each wave writes its lanes' 80 values into its own
-// LDS tile, 32 lanes at a time, which leaves as 16-byte vectors in the order of those 10 240 bytes (float32).
+// LDS tile (all 64 lanes in float32, 32 at a time in float64), which leaves as 16-byte vectors in the order of those
+// 20 480 bytes.
 template <typename T, int MODE, bool NOISE = false>
 __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> p, const ResetArgs rs, const AutoArgs au, const NoiseArgs nz, const int* __restrict__ actions,
                                                        T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ hist_g,
@@ -65,6 +65,9 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
     // Every lane's 80 values sit PAD apart: with the rows back to back (80 dwords) the lanes' 16-byte writes fall on
     // 2 of the 8 four-bank groups, a 32-way conflict; at 84 they spread over all of them.
     constexpr int PAD = COBS + 16 / (int)sizeof(T);
+    // agent-rows a wave's tile holds: all 64 of its lanes' rows in float32 (21 KB a wave, 66 KB a workgroup: two
+    // workgroups per CU, which is what the registers allow anyway), half of them at a time in float64
+    constexpr int TROWS = sizeof(T) == 4 ? 64 : 32;
     __shared__ __attribute__((aligned(32))) T tiles[NT / 64][TROWS * PAD];
     __shared__ T xch[CA * 4 * XS];       // [agent][px, py, vx, vy][world]: the newest state, also the history slot's image
     __shared__ T rsum[NT];
