@@ -3,8 +3,9 @@
 Bars: float64 kernels within 1e-9 (relative, with a 1e-12 absolute floor) of the reference after
 25 free-running steps; float32 kernels within 1e-4; integer fields (collision counts, occupied
 landmarks, forest / visibility masks, done) bit-exact for float64.  For float32 an integer field
-may legitimately differ where a distance sits within float32 rounding of its threshold, so those
-are compared only on envs whose float64 margin to every threshold exceeds 1e-5.
+may legitimately differ where a distance sits within the float32 drift of its threshold; everywhere
+else (the reference's float64 state decides the test with a 4e-4 margin) it must be bit-exact too, at
+every step of a free-running episode.
 """
 import numpy as np
 import pytest
@@ -113,6 +114,60 @@ def test_fp32_trajectory_within_1e4(case):
     same = np.all(_unpack_info(case, env, info_i, info_f)["collisions"] == g["collisions"][T - 1], axis=1)
     assert same.mean() > 0.9
     assert _close(rew.cpu().numpy()[same], g["rew"][T - 1][same], 1e-4, 2e-4)
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_fp32_integer_fields_are_exact_away_from_thresholds(case):
+    """Every integer field of the float32 kernel, at every step of a free-running episode, equals the
+    reference's wherever the reference's own float64 state decides it with a margin.
+
+    float32 positions stay within 1e-4 (+1e-4 relative) of the reference's, so a distance between two
+    entities is off by less than 4e-4.  An env is decisive at step t when the oracle, evaluated on the
+    reference's state, returns the same integers with every entity 2e-4 larger and 2e-4 smaller (every
+    contact / forest threshold moved by +-4e-4) and, for simple_spread, no landmark's nearest agent is
+    within 4e-4 of the 0.1 occupancy radius.  There the float32 integers must be the reference's, bit for
+    bit; the rewards, whose jumps are those integers, must then agree to the float32 tolerance."""
+    import dataclasses
+    g = load_golden(case)
+    T, B, _ = g["actions"].shape
+    scn, kw = GOLDEN_CASES[case]
+    spec = orc.make_spec(scn, **kw)
+    A, L, shift = spec.A, spec.L, 2e-4
+    moved = [dataclasses.replace(spec, size=spec.size + s) for s in (shift, -shift)]
+
+    def ints(sp, pos):
+        out = [orc.info(sp, pos)["collisions"].reshape(B, -1)]
+        if case == "world_comm":
+            inf, vis = orc.visibility_masks(sp, pos)
+            out += [inf.reshape(B, -1), vis.reshape(B, -1)]
+            # the good agents' food contacts are jumps of their reward (simple_world_comm.py:178-180)
+            out += [np.stack([orc._is_collision(pos, i, A + f, sp.size) for i in range(A) if not sp.adversary[i] for f in sp.food], axis=1)]
+        return np.concatenate([o.astype(np.int64) for o in out], axis=1)
+
+    env = _env(case, B, torch.float32)
+    env.set_state(g["pos0"], g["vel0"])
+    pos = np.array(g["pos0"], np.float64)
+    decisive_total = 0
+    for t in range(T):
+        obs, rew, done, (info_i, info_f) = env.step(torch.as_tensor(g["actions"][t]))
+        got_pos = env.get_state()[0]
+        assert _close(got_pos[:, :A], g["pos"][t], 1e-4, 1e-4), (case, t)
+        pos[:, :A] = g["pos"][t]
+        decisive = np.all(ints(moved[0], pos) == ints(moved[1], pos), axis=1)
+        if case == "spread3":
+            nearest = np.stack([np.sqrt(((pos[:, :A] - pos[:, A + l:A + l + 1]) ** 2).sum(axis=2)).min(axis=1) for l in range(L)], axis=1)
+            decisive &= np.all(np.abs(nearest - 0.1) > 2 * shift, axis=1)
+        decisive_total += int(decisive.sum())
+        inf = _unpack_info(case, env, info_i, info_f)
+        assert np.array_equal(inf["collisions"][decisive], g["collisions"][t][decisive]), (case, t)
+        if case == "spread3":
+            assert np.array_equal(inf["occupied"][decisive], g["occupied"][t][decisive]), (case, t)
+        if case == "world_comm":
+            assert np.array_equal(inf["in_forest"][decisive], g["in_forest"][t][decisive]), (case, t)
+            assert np.array_equal(inf["visible"][decisive], g["visible"][t][decisive]), (case, t)
+        assert _close(rew.cpu().numpy()[decisive], g["rew"][t][decisive], 1e-4, 2e-4), (case, t)
+    # the fixtures seed some envs onto thresholds on purpose; most env-steps are still decided with a margin
+    assert decisive_total > 0.8 * T * B, (case, decisive_total, T * B)
 
 
 @pytest.mark.parametrize("case", SMALL_CASES)
