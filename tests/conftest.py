@@ -38,6 +38,30 @@ CLASSIC_CASES = ["simple", "simple_adversary", "simple_push"]
 COMM_CASES = ["simple_speaker_listener", "simple_reference", "simple_crypto"]
 
 
+def decided_with_margin(size, pos, margin, ordered=()):
+    """Envs [B] (bool) whose integer outcomes cannot depend on a position error below `margin`.
+
+    Every contact, forest, pick-up and hand-over test of the scenarios is ||p_a - p_b|| < size_a + size_b
+    for some pair of entities: an env passes when every pair's distance is further than `margin` from that
+    sum.  `ordered` lists (entity, candidates) groups whose distances the scenario sorts (collector's
+    nearest-first lists): there the distances from the entity to two candidates must differ by more than
+    `margin`, unless the two candidates sit on the very same point (an exact tie in any precision, which
+    the scenario breaks by index)."""
+    pos = np.asarray(pos, np.float64)
+    size = np.asarray(size, np.float64)
+    d = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(axis=3))            # [B, E, E]
+    gap = np.abs(d - (size[:, None] + size[None, :]))
+    E = pos.shape[1]
+    ok = np.all(gap[:, ~np.eye(E, dtype=bool)] > margin, axis=1)
+    for e, cand in ordered:
+        cand = list(cand)
+        for x in range(len(cand)):
+            for y in range(x + 1, len(cand)):
+                same_point = np.all(pos[:, cand[x]] == pos[:, cand[y]], axis=1)
+                ok &= (np.abs(d[:, e, cand[x]] - d[:, e, cand[y]]) > margin) | same_point
+    return ok
+
+
 @pytest.fixture(scope="session")
 def golden():
     return {k: load_golden(k) for k in GOLDEN_CASES}

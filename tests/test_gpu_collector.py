@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
-from conftest import load_golden
+from conftest import decided_with_margin, load_golden
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -70,6 +70,11 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
     exact = dtype == "float64"
     if exact:
         assert _close(env.obs.cpu().numpy(), g["obs0"], rtol, atol)
+    spec = orc.make_spec(CASE)
+    L = spec.L
+    # nearest-first lists: every agent orders the other agents and the treasures by distance (collector.py:268-295)
+    ordered = [(i, [j for j in range(A) if j != i]) for i in range(A)] + [(i, list(range(A, A + L))) for i in range(A)]
+    sure_total = 0
     for t in range(T):
         pos, vel, holding, ttype, alive = _state_before(g, t)
         env.set_state(pos, vel, goal=_aux(holding, ttype, alive))
@@ -79,24 +84,26 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
         assert _close(gv, g["vel"][t], rtol * 10, atol * 10), t
         ii = info_i.cpu().numpy()
         h2, t2, a2 = _unword(env.aux[0].cpu().numpy())
-        if exact:
-            assert _close(obs.cpu().numpy(), g["obs"][t], rtol, atol), (t, np.abs(obs.cpu().numpy() - g["obs"][t]).max())
-            assert _close(rew.cpu().numpy(), g["rew"][t], rtol, atol), (t, np.abs(rew.cpu().numpy() - g["rew"][t]).max())
-            assert np.array_equal(ii[:, :3 * A].reshape(B, A, 3), g["info"][t]) and np.array_equal(ii[:, 3 * A], _word(holding, ttype, alive))
-            assert np.array_equal(h2, g["holding"][t]) and np.array_equal(a2, g["alive"][t]), t
-            keep = alive & a2
-            assert np.array_equal(t2[keep], g["ttype"][t][keep])
-        else:
-            # float32 may reorder two near-equidistant neighbours or flip a knife-edge contact of the fixture
-            ok = np.all(np.abs(obs.cpu().numpy() - g["obs"][t]) <= atol + rtol * np.abs(g["obs"][t]), axis=1)
-            assert ok.mean() > 0.85, (t, ok.mean())
-            assert np.mean(np.all(h2 == g["holding"][t], axis=1)) > 0.9
+        # float32 may reorder two near-equidistant neighbours or flip a knife-edge contact of the fixture: the float64
+        # kernel must agree everywhere, the float32 kernel in every env whose contacts and nearest-first orders the
+        # reference's own positions decide with a 4e-4 margin (the position tolerance is 1e-4)
+        after = pos.copy()
+        after[:, :A] = g["pos"][t]
+        sure = np.ones(B, bool) if exact else decided_with_margin(spec.size, after, 4e-4, ordered)
+        sure_total += int(sure.sum())
+        assert _close(obs.cpu().numpy()[sure], g["obs"][t][sure], rtol, atol), (t, np.abs(obs.cpu().numpy() - g["obs"][t])[sure].max())
+        assert _close(rew.cpu().numpy()[sure], g["rew"][t][sure], rtol, 2 * atol), (t, np.abs(rew.cpu().numpy() - g["rew"][t])[sure].max())
+        assert np.array_equal(ii[sure, :3 * A].reshape(-1, A, 3), g["info"][t][sure]) and np.array_equal(ii[:, 3 * A], _word(holding, ttype, alive))
+        assert np.array_equal(h2[sure], g["holding"][t][sure]) and np.array_equal(a2[sure], g["alive"][t][sure]), t
+        keep = alive & a2 & sure[:, None]
+        assert np.array_equal(t2[keep], g["ttype"][t][keep])
         assert not done.any()
         tre = gp[:, A:]
         assert np.array_equal(tre[alive & a2], pos[:, A:][alive & a2].astype(tre.dtype))
         assert np.all(tre[~a2] == 0.0)                                  # taken: parked at the origin
         assert np.all(np.abs(tre[~alive]) <= 0.95) and a2[~alive].all()  # respawned inside the arena
         assert np.array_equal(env.aux[2].cpu().numpy(), (~alive).sum(axis=1))
+    assert sure_total > 0.7 * T * B, (sure_total, T * B)
 
 
 def test_free_running_until_first_respawn_matches_reference():

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
-from conftest import load_golden
+from conftest import decided_with_margin, load_golden
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -63,6 +63,8 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
     env.observe()
     assert _close(env.obs.cpu().numpy(), g["obs0"], rtol, atol)
     exact = dtype == "float64"
+    spec = orc.make_spec(CASE)
+    sure_total = 0
     for t in range(T):
         pos, vel, alive, holding = _state_before(g, t)
         env.set_state(pos, vel, goal=_aux(alive, holding))
@@ -70,18 +72,18 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
         gp, gv, _ = env.get_state()
         assert _close(gp[:, :A], g["pos"][t], rtol, atol), (t, np.abs(gp[:, :A] - g["pos"][t]).max())
         assert _close(gv, g["vel"][t], rtol * 10, atol * 10), t
-        # float32 may flip a threshold test of the fixture's knife-edge placements (distance within 1e-4 of a
-        # contact radius); the float64 kernel must agree everywhere
+        # float32 may flip a threshold test of the fixture's knife-edge placements (a distance within the float32
+        # error of a contact radius): the float64 kernel must agree everywhere, the float32 kernel in every env whose
+        # tests the reference's own positions decide with a 4e-4 margin (the position tolerance is 1e-4)
         ii = info_i.cpu().numpy()
-        if exact:
-            assert _close(obs.cpu().numpy(), g["obs"][t], rtol, atol), t
-            assert _close(rew.cpu().numpy(), g["rew"][t], rtol, atol), t
-            assert np.array_equal(ii[:, :A], g["collisions"][t]) and np.array_equal(ii[:, A], _flags(alive, holding))
-            assert np.array_equal(env.aux[0].cpu().numpy(), _flags(g["alive"][t], g["holding"][t])), t
-        else:
-            ok = np.all(np.abs(obs.cpu().numpy() - g["obs"][t]) <= atol + rtol * np.abs(g["obs"][t]), axis=1)
-            assert ok.mean() > 0.9, t
-            assert np.mean(env.aux[0].cpu().numpy() == _flags(g["alive"][t], g["holding"][t])) > 0.9
+        after = pos.copy()
+        after[:, :A] = g["pos"][t]
+        sure = np.ones(B, bool) if exact else decided_with_margin(spec.size, after, 4e-4)
+        sure_total += int(sure.sum())
+        assert _close(obs.cpu().numpy()[sure], g["obs"][t][sure], rtol, atol), t
+        assert _close(rew.cpu().numpy()[sure], g["rew"][t][sure], rtol, 2 * atol), t
+        assert np.array_equal(ii[sure, :A], g["collisions"][t][sure]) and np.array_equal(ii[:, A], _flags(alive, holding))
+        assert np.array_equal(env.aux[0].cpu().numpy()[sure], _flags(g["alive"][t], g["holding"][t])[sure]), t
         assert not done.any()
         # food: eaten ones are parked at -999, untouched ones keep their place, respawned ones land in the arena
         food = gp[:, A + 1:A + 4]
@@ -92,6 +94,7 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
         assert np.all(np.abs(food[~was_alive]) <= 0.95) and now_alive[~was_alive].all()
         # the respawn stream advanced by the number of respawns
         assert np.array_equal(env.aux[2].cpu().numpy(), (~was_alive).sum(axis=1))
+    assert sure_total > 0.8 * T * B, (sure_total, T * B)
 
 
 def test_free_running_until_first_respawn_matches_reference():
