@@ -330,3 +330,30 @@ def test_device_noise_stream_is_standard_normal():
     assert not nc[:, 1:].any()                                  # silent agents draw nothing
     nu2, _ = orc.device_noise(spec, seed=5, step=4, B=8)
     assert not np.array_equal(nu[:8], nu2)
+
+
+@pytest.mark.parametrize("case", ["tag", "world_comm"])
+def test_decided_with_margin_marks_envs_whose_integers_survive_perturbation(case):
+    """The filter the float32 GPU tests use to demand bit-exact integers: in an env it passes, moving every
+    entity by less than a quarter of the margin in any direction leaves the oracle's collision counts and
+    forest / visibility masks as they are; the fixtures also hold envs it must reject (seeded onto thresholds)."""
+    from conftest import decided_with_margin
+    scn, kw = GOLDEN_CASES[case]
+    g = load_golden(case)
+    spec = orc.make_spec(scn, **kw)
+    A, margin = spec.A, 4e-4
+    rng = np.random.RandomState(5)
+    pos = g["pos0"].copy()
+    rejected = 0
+    for t in range(0, g["actions"].shape[0], 4):
+        pos[:, :A] = g["pos"][t]
+        sure = decided_with_margin(spec.size, pos, margin)
+        rejected += int((~sure).sum())
+        want = orc.info(spec, pos)["collisions"]
+        for _ in range(8):
+            moved = pos + rng.uniform(-margin / 4, margin / 4, pos.shape) / np.sqrt(2.0)
+            assert np.array_equal(orc.info(spec, moved)["collisions"][sure], want[sure]), (case, t)
+            if case == "world_comm":
+                for a, b in zip(orc.visibility_masks(spec, moved), orc.visibility_masks(spec, pos)):
+                    assert np.array_equal(a[sure], b[sure]), (case, t)
+    assert rejected > 0
