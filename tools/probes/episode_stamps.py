@@ -58,3 +58,7 @@ for lo, hi in ((0, 32), (32, 64), (64, 96), (96, 128)):
     d = dur[(idx >= lo) & (idx < hi)]
     print("  slots %3d-%3d: min %.1f med %.1f max %.1f" % (lo, hi, d.min(), np.median(d), d.max()))
 np.save(os.path.join(ROOT, "gpurun_out", "stamps.npy"), st)
+end = us[:, 60]
+print("end of the last wave by blockIdx % 8 (launches with several rounds of waves end with the slowest XCD):")
+for x in range(8):
+    print("  xcd %d: last wave ends at %.1f us, mean lifetime %.1f us" % (x, end[x::8].max(), dur[x::8].mean()))
