@@ -1,4 +1,5 @@
 // Diagnostic: what the reward rows of an episode launch cost by the shape of their store.
+// usage: rew_shapes <worlds> [dependent instructions between steps, default 0]
 // Each 64-lane wave owns 64 envs; per step it writes 10752 B of observations (16-byte vectors, whole lines) and its
 // 768 B of rewards ([B][3] floats) in one of several shapes.   hipcc --offload-arch=gfx950 -O3
 //   0 no rewards                         1 48 lanes x 16 B (one masked instruction, as the kernels do)
@@ -13,11 +14,12 @@
 struct F3 { float x, y, z; };
 
 template <int VARIANT>
-__global__ __launch_bounds__(64) void k(float4* obs, float* rew, long long B, int T) {
+__global__ __launch_bounds__(64) void k(float4* obs, float* rew, long long B, int T, int work) {
     const int lane = threadIdx.x;
     const long long env0 = (long long)blockIdx.x * 64;
     float4 v = make_float4(lane, 1.f, 2.f, 3.f);
     for (int t = 0; t < T; ++t) {
+        for (int i = 0; i < work; ++i) v.y = v.y * 1.0001f + v.z;      // a step's arithmetic: `work` dependent instructions
         const long long row0 = (long long)t * B + env0;
         float4* o = obs + row0 * 42 / 4;
         float* r = rew + row0 * 3;
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(64) void k(float4* obs, float* rew, long long B, in
 int main(int argc, char** argv) {
     long long B = argc > 1 ? atoll(argv[1]) : 65536;
     int T = 24;
+    int work = argc > 2 ? atoi(argv[2]) : 0;      // dependent instructions between two steps' stores
     float4* obs; float* rew;
     CK(hipMalloc(&obs, (size_t)T * B * 168)); CK(hipMalloc(&rew, (size_t)T * B * 12));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -51,17 +54,17 @@ int main(int argc, char** argv) {
             const int N = 20;
             for (int i = 0; i < N; ++i) {
                 const dim3 g(B / 64), b(64);
-                if (variant == 0) hipLaunchKernelGGL(k<0>, g, b, 0, 0, obs, rew, B, T);
-                if (variant == 1) hipLaunchKernelGGL(k<1>, g, b, 0, 0, obs, rew, B, T);
-                if (variant == 2) hipLaunchKernelGGL(k<2>, g, b, 0, 0, obs, rew, B, T);
-                if (variant == 3) hipLaunchKernelGGL(k<3>, g, b, 0, 0, obs, rew, B, T);
-                if (variant == 4) hipLaunchKernelGGL(k<4>, g, b, 0, 0, obs, rew, B, T);
-                if (variant == 5) hipLaunchKernelGGL(k<5>, g, b, 0, 0, obs, rew, B, T);
+                if (variant == 0) hipLaunchKernelGGL(k<0>, g, b, 0, 0, obs, rew, B, T, work);
+                if (variant == 1) hipLaunchKernelGGL(k<1>, g, b, 0, 0, obs, rew, B, T, work);
+                if (variant == 2) hipLaunchKernelGGL(k<2>, g, b, 0, 0, obs, rew, B, T, work);
+                if (variant == 3) hipLaunchKernelGGL(k<3>, g, b, 0, 0, obs, rew, B, T, work);
+                if (variant == 4) hipLaunchKernelGGL(k<4>, g, b, 0, 0, obs, rew, B, T, work);
+                if (variant == 5) hipLaunchKernelGGL(k<5>, g, b, 0, 0, obs, rew, B, T, work);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             double bytes = (double)T * B * (168 + (variant >= 1 ? 12 : 0));
-            if (rep == 2) printf("B=%lld variant=%d  %.1f us/launch  %.0f GB/s\n", B, variant, ms * 1e3 / N, bytes / (ms * 1e-3 / N) / 1e9);
+            if (rep == 2) printf("B=%lld work=%d variant=%d  %.1f us/launch  %.0f GB/s\n", B, work, variant, ms * 1e3 / N, bytes / (ms * 1e-3 / N) / 1e9);
         }
     }
     return 0;
