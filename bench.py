@@ -29,7 +29,8 @@ processes, before anything touches the GPU); under torch.distributed.run it join
 Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   roofline      HBM roofline of the dominant kernel; achieved = algorithmic bytes per launch /
                 average launch duration from HIP event pairs inside the timed region, each
-                bracketing 4 consecutive launches (every 4th group by default, --event-every)
+                bracketing 4 consecutive launches (every 4th group by default, --event-every);
+                traffic / valu = the rocprofv3 counter figures stored for this very build (null otherwise)
   cpu_baseline  the single-env numpy oracle (oracle/mpe_oracle.py) timed on this host, 1 core; its
                 "n_process" entry is the same loop in --cpu-procs processes, one env each
   step_mode     the same workload issued as one mpe_step launch per step (hipGraph), for comparison
@@ -99,6 +100,23 @@ def stored_traffic(key):
     if entry.get("source_hash") != source_hash():
         return None
     return entry.get("hbm_bytes_per_launch")
+
+def stored_valu(key):
+    """VALU figures of the dominant kernel from the rocprofv3 counter pass (profiles/*valu*.json, written by
+    tools/collect_profiles.py), or None when none was measured on this build of the kernels."""
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*valu*.json")), reverse=True):
+        try:
+            entry = json.load(open(fn)).get(key)
+        except (OSError, ValueError, AttributeError):
+            continue
+        if isinstance(entry, dict) and entry.get("source_hash") == source_hash() and "valu_insts_per_wave" in entry:
+            return {"insts_per_wave": entry["valu_insts_per_wave"],
+                    "issue_fraction_of_wave_lifetime": entry["valu_issue_fraction_of_wave_lifetime"],
+                    "cycles_per_inst_while_issuing": entry["cycles_per_valu_inst_while_issuing"],
+                    "source": "profiles/" + os.path.basename(fn)}
+    return None
+
 
 # Algorithmic bytes per env-step, float32 (s = 4), int32 actions, 1-byte done.
 #   step launch:    reads  agent pos+vel 4A*s, landmark pos 2L*s, actions 4*n_act
@@ -476,6 +494,8 @@ def main():
                          # counters are not collected in a timing run: the figure is the stored rocprofv3 measurement
                          # of this very build of the kernels, null otherwise
                          "traffic": stored_traffic("%s_%s_B%d_%s" % (args.scenario, args.dtype, B, args.mode)),
+                         # VALU use of the same kernel, from the same kind of stored counter pass (null otherwise)
+                         "valu": stored_valu("%s_%s_B%d_%s" % (args.scenario, args.dtype, B, args.mode)),
                          "kernel": "%s<%s, %s, %s>" % ("consensus_kernel" if args.scenario == "consensus" else ("wave_kernel" if env.env_major else "small_kernel"),
                                                        "float" if s == 4 else "double", args.scenario, "rollout" if args.mode == "rollout" else "step"),
                          "bytes_per_env_step": bytes_env_step, "bytes_per_launch": bytes_launch,

@@ -67,6 +67,20 @@ def test_stored_traffic_is_refused_for_another_build(tmp_path, monkeypatch):
     assert bench.stored_traffic("missing") is None
 
 
+def test_stored_valu_is_refused_for_another_build(tmp_path, monkeypatch):
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_hash", lambda: "aaaa")
+    fig = {"valu_insts_per_wave": 6500.0, "valu_issue_fraction_of_wave_lifetime": 0.25, "cycles_per_valu_inst_while_issuing": 4.3}
+    (prof / "r01_valu.json").write_text(json.dumps({"k": dict(fig, source_hash="bbbb")}))
+    assert bench.stored_valu("k") is None
+    (prof / "r02_valu_x.json").write_text(json.dumps({"k": dict(fig, source_hash="aaaa")}))
+    got = bench.stored_valu("k")
+    assert got["insts_per_wave"] == 6500.0 and got["source"] == "profiles/r02_valu_x.json"
+    assert bench.stored_valu("missing") is None
+
+
 def test_source_hash_is_stable():
     assert bench.source_hash() == bench.source_hash() and len(bench.source_hash()) == 16
 
