@@ -75,3 +75,31 @@ def test_library_was_built_from_these_sources():
     if not os.path.exists(note):
         pytest.skip("library not built by __graft_entry__.build()")
     assert open(note).read().strip() == bench.source_hash(), "run `python __graft_entry__.py build`"
+
+
+def test_the_product_has_no_cpu_path():
+    """Without a GPU device the batch API refuses to start, and without the built library the package does not load:
+    nothing falls back to a CPU implementation."""
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, "multiagent-particle-envs_amd")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch, mpe_hip\n"
+            "try:\n"
+            "    mpe_hip.BatchedEnv('simple_spread', 8, device='cpu')\n"
+            "except ValueError as e:\n"
+            "    print('REFUSED', e)\n" % pkg)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "REFUSED" in r.stdout and "no CPU path" in r.stdout, r.stdout + r.stderr
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import mpe_hip\n"
+            "from mpe_hip import _lib\n"
+            "_lib.load()\n" % pkg)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MPE_HIP_LIB="/nonexistent/libmpe_hip.so"))
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr, r.stderr[-1500:]
+    # the product package never imports the oracle
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                assert "mpe_oracle" not in open(os.path.join(dirpath, fn)).read(), os.path.join(dirpath, fn)
