@@ -37,3 +37,45 @@ def test_episode_launch_equals_reset_and_steps(scenario, B):
         x, y = getattr(e1, k, None), getattr(e2, k, None)
         if x is not None:
             assert torch.equal(x, y), k
+
+
+LONG = ["simple_spread", "simple_tag", "simple_world_comm", "simple_reference", "simple_predator_prey", "collector", "consensus", "spread_9_4"]
+
+
+@pytest.mark.parametrize("T", [1, 29, 71])
+@pytest.mark.parametrize("scenario", LONG)
+def test_long_and_short_rollouts_equal_stepping(scenario, T):
+    """Launches of 1, 29 and 71 steps: shorter than, just beyond and several times the actions a lane holds between two
+    fetches (28 steps of simple_spread, 33 of simple_tag, 6 of simple_world_comm and simple_predator_prey, 32 of
+    consensus, every step of the wave-per-world kernel), ending in the middle of a fetch, on a batch with a ragged
+    tail.  State, every step's outputs and (consensus) the history ring must be the bits single steps give."""
+    import mpe_hip
+    B = 200
+    kw = dict(n_agents=9, n_landmarks=4) if scenario == "spread_9_4" else {}
+    name = "simple_spread" if scenario == "spread_9_4" else scenario
+    for dtype in (torch.float32, torch.float64):
+        e1 = mpe_hip.BatchedEnv(name, B, dtype=dtype, device="cuda:0", info=False, **kw)
+        e2 = mpe_hip.BatchedEnv(name, B, dtype=dtype, device="cuda:0", info=False, **kw)
+        gen = torch.Generator("cuda:0").manual_seed(100 * T + B)
+        a = torch.randint(0, 5, (T, B, e1.n_act), dtype=torch.int32, device="cuda:0", generator=gen)
+        for col, n in enumerate(e1.action_dims):
+            if n != 5:
+                a[:, :, col] = torch.randint(0, n, (T, B), dtype=torch.int32, device="cuda:0", generator=gen)
+        e1.reset(seed=5)
+        e2.reset(seed=5)
+        out = e2.rollout(a)
+        for t in range(T):
+            obs, rew, done, _ = e1.step(a[t])
+            assert torch.equal(obs, out["obs"][t]), (scenario, dtype, t, "obs")
+            assert torch.equal(rew, out["rew"][t]), (scenario, dtype, t, "rew")
+            assert torch.equal(done, out["done"][t]), (scenario, dtype, t, "done")
+        for k in ("pos", "vel", "aux"):
+            x, y = getattr(e1, k, None), getattr(e2, k, None)
+            if x is not None:
+                assert torch.equal(x, y), (scenario, dtype, k)
+        if e1.comm is not None:
+            if scenario == "consensus":
+                for x, y in zip(e1.get_history(), e2.get_history()):
+                    assert (x == y).all(), (scenario, dtype, "history")
+            else:
+                assert torch.equal(e1.comm, e2.comm), (scenario, dtype, "comm")
