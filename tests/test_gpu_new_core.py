@@ -146,3 +146,61 @@ def test_new_core_world_facade_replays_the_reference():
     assert np.array_equal(w.cached_dist_vect[2, 5], pos[2] - pos[5]) and np.array_equal(w.cached_dist_vect[5, 2], -(pos[2] - pos[5]))
     assert np.array_equal(w.cached_dist_mag[1, 8], np.sqrt(np.sum(np.square(pos[1] - pos[8]))))
     assert w.cached_collisions.shape == (A + L, A + L)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_world_step_on_random_worlds_matches_oracle(seed):
+    """mpe_world_step on worlds nobody designed: 1..64 agents and 0..64 landmarks with random sizes, masses, collide /
+    movable / silent / ghost flags, speed limits, up to four random walls (hard and soft, entities near their rounded
+    ends), random dt and damping, under the physics of core.py (even seeds) and new_core.py with random accel (odd
+    seeds).  Every step starts from the oracle's state; the float64 kernel must stay within 1e-11."""
+    import mpe_hip
+    rng = np.random.RandomState(4000 + seed)
+    A, L = int(rng.randint(1, 65)), int(rng.randint(0, 65))
+    if seed == 0:
+        A, L = 64, 64
+    if seed == 1:
+        A, L = 1, 0
+    E = A + L
+    new_core = seed % 2 == 1
+    size = rng.uniform(0.02, 0.2, E)
+    mass = rng.uniform(0.5, 3.0, E)
+    collide = rng.rand(E) < 0.6
+    movable = np.r_[rng.rand(A) < 0.85, np.zeros(L, bool)]
+    sens = rng.uniform(1.0, 5.0, A)
+    max_speed = np.where(rng.rand(A) < 0.5, np.inf, rng.uniform(0.3, 1.5, A))
+    silent = rng.rand(A) < 0.8
+    dim_c = int(rng.randint(1, 5))
+    ghost = rng.rand(A) < 0.3
+    accel = np.where(rng.rand(A) < 0.3, np.nan, rng.uniform(1.0, 4.0, A)) if new_core else None
+    walls = []
+    for _ in range(int(rng.randint(0, 5))):
+        lo, hi = np.sort(rng.uniform(-1.0, 1.0, 2))
+        walls.append(dict(orient="HV"[int(rng.randint(2))], axis_pos=float(rng.uniform(-1, 1)), endpoints=(float(lo), float(hi)),
+                          width=float(rng.uniform(0.05, 0.3)), hard=bool(rng.rand() < 0.5)))
+    dt, damping = float(rng.uniform(0.05, 0.15)), float(rng.uniform(0.1, 0.4))
+    spec = orc.Spec("physics", A, L, dim_c, size, movable, collide, mass, sens=sens, max_speed=max_speed, silent=silent,
+                    adversary=np.zeros(A, bool), leader=np.zeros(A, bool), dt=dt, damping=damping, walls=walls, ghost=ghost,
+                    new_core=new_core, accel=accel)
+    kw = dict(new_core=True, accel=accel) if new_core else {}
+    phys = mpe_hip.physics_spec(A, L, dim_c, size, mass, collide, sens, max_speed, silent, walls=walls, ghost=ghost, movable=movable,
+                                dt=dt, damping=damping, **kw)
+    B = 40
+    env = mpe_hip.BatchedEnv(phys, B, dtype=torch.float64)
+    speakers = [i for i in range(A) if not silent[i]]
+    pos = rng.uniform(-0.7, 0.7, (B, E, 2))         # dense: many contacts, entities beside and beyond the walls' ends
+    vel = rng.uniform(-1, 1, (B, A, 2))
+    worst = 0.0
+    for t in range(4):
+        u = rng.uniform(-1, 1, (B, A, 2)) * sens[None, :, None]
+        c = rng.uniform(0, 1, (B, A, dim_c))
+        env.set_state(pos, vel)
+        env.world_step(u.reshape(B, -1), c[:, speakers, :].reshape(B, -1) if speakers else None)
+        pos, vel, comm = orc.world_step(spec, pos, vel, u, c)
+        g_pos, g_vel, g_comm = env.get_state()
+        scale = 1.0 + np.abs(vel).max()
+        worst = max(worst, np.abs(g_pos - pos).max() / scale, np.abs(g_vel - vel).max() / scale)
+        if speakers:
+            assert np.array_equal(g_comm, comm[:, speakers, :].reshape(B, -1))
+        assert np.array_equal(g_pos[:, ~movable], pos[:, ~movable])         # what cannot move stays bit for bit
+    assert worst < 1e-11, (A, L, new_core, len(walls), worst)
