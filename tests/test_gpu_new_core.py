@@ -153,7 +153,8 @@ def test_world_step_on_random_worlds_matches_oracle(seed):
     """mpe_world_step on worlds nobody designed: 1..64 agents and 0..64 landmarks with random sizes, masses, collide /
     movable / silent / ghost flags, speed limits, up to four random walls (hard and soft, entities near their rounded
     ends), random dt and damping, under the physics of core.py (even seeds) and new_core.py with random accel (odd
-    seeds).  Every step starts from the oracle's state; the float64 kernel must stay within 1e-11."""
+    seeds).  Every step starts from the oracle's state; the float64 kernel must stay within 1e-11, the float32 kernel within 1e-4
+    (both relative to 1 + the largest speed in the batch)."""
     import mpe_hip
     rng = np.random.RandomState(4000 + seed)
     A, L = int(rng.randint(1, 65)), int(rng.randint(0, 65))
@@ -187,6 +188,8 @@ def test_world_step_on_random_worlds_matches_oracle(seed):
                                 dt=dt, damping=damping, **kw)
     B = 40
     env = mpe_hip.BatchedEnv(phys, B, dtype=torch.float64)
+    env32 = mpe_hip.BatchedEnv(phys, B, dtype=torch.float32)
+    worst32 = 0.0
     speakers = [i for i in range(A) if not silent[i]]
     pos = rng.uniform(-0.7, 0.7, (B, E, 2))         # dense: many contacts, entities beside and beyond the walls' ends
     vel = rng.uniform(-1, 1, (B, A, 2))
@@ -196,7 +199,11 @@ def test_world_step_on_random_worlds_matches_oracle(seed):
         c = rng.uniform(0, 1, (B, A, dim_c))
         env.set_state(pos, vel)
         env.world_step(u.reshape(B, -1), c[:, speakers, :].reshape(B, -1) if speakers else None)
+        env32.set_state(pos, vel)
+        env32.world_step(u.reshape(B, -1), c[:, speakers, :].reshape(B, -1) if speakers else None)
         pos, vel, comm = orc.world_step(spec, pos, vel, u, c)
+        p32, v32, _ = env32.get_state()
+        worst32 = max(worst32, np.abs(p32 - pos).max() / (1.0 + np.abs(vel).max()), np.abs(v32 - vel).max() / (1.0 + np.abs(vel).max()))
         g_pos, g_vel, g_comm = env.get_state()
         scale = 1.0 + np.abs(vel).max()
         worst = max(worst, np.abs(g_pos - pos).max() / scale, np.abs(g_vel - vel).max() / scale)
@@ -204,3 +211,4 @@ def test_world_step_on_random_worlds_matches_oracle(seed):
             assert np.array_equal(g_comm, comm[:, speakers, :].reshape(B, -1))
         assert np.array_equal(g_pos[:, ~movable], pos[:, ~movable])         # what cannot move stays bit for bit
     assert worst < 1e-11, (A, L, new_core, len(walls), worst)
+    assert worst32 < 1e-4, (A, L, new_core, len(walls), worst32)        # the float32 kernel, same single steps
