@@ -309,6 +309,31 @@ class BatchedEnv:
         comm = lay(self.comm).cpu().numpy() if self.comm is not None else None
         return pos, vel, comm
 
+    _STATE_FIELDS = ("pos", "vel", "comm", "aux", "step_count", "episode_count", "ep_return", "last_return")
+
+    def state_dict(self):
+        """Checkpoint of the batch: copies (on the device) of everything its future depends on -- positions,
+        velocities, comm state or history ring, the scenarios' int state, the episode bookkeeping of
+        ``max_episode_steps`` -- plus the episode numbering of the resets.  ``load_state_dict`` on an env built with
+        the same arguments resumes bit for bit; the dict holds tensors and ints only (``torch.save`` takes it).  Not
+        included: the step number of the device's noise generator (call ``set_noise`` again after loading)."""
+        return {"scenario": self.spec.name, "n_envs": self.n_envs, "dtype": str(self.dtype), "env_major": self.env_major,
+                "episode": self._episode, "seed": self.seed, "auto_since_reset": self._auto_since_reset,
+                "tensors": {k: getattr(self, k).clone() for k in self._STATE_FIELDS if getattr(self, k, None) is not None}}
+
+    def load_state_dict(self, sd):
+        """Restore a ``state_dict`` taken from an env of the same scenario, size, dtype and bookkeeping."""
+        have = [k for k in self._STATE_FIELDS if getattr(self, k, None) is not None]
+        if (sd["scenario"], sd["n_envs"], sd["dtype"]) != (self.spec.name, self.n_envs, str(self.dtype)) or sorted(sd["tensors"]) != sorted(have):
+            raise ValueError("checkpoint of %s x %d (%s, fields %s) does not fit this env: %s x %d (%s, fields %s)"
+                             % (sd["scenario"], sd["n_envs"], sd["dtype"], sorted(sd["tensors"]), self.spec.name, self.n_envs, self.dtype, sorted(have)))
+        for k in have:
+            t = sd["tensors"][k]
+            if tuple(t.shape) != tuple(getattr(self, k).shape):
+                raise ValueError("checkpoint field %s has shape %s, expected %s" % (k, tuple(t.shape), tuple(getattr(self, k).shape)))
+            getattr(self, k).copy_(t)
+        self._episode, self.seed, self._auto_since_reset = int(sd["episode"]), int(sd["seed"]), bool(sd["auto_since_reset"])
+
     def set_history(self, his_pos, his_vel):
         """consensus: the agents' last ten positions and velocities, [B, A, 10, 2] each, oldest first
         (state.p_his_pos / p_his_vel); stored as the history ring with its head at slot 0."""
