@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     __shared__ T size_s[MAX_E];
     __shared__ int coll_idx[MAX_E];     // indices of the colliding entities, ascending
     __shared__ T mind_s[MPE_MAX_LANDMARKS];
-    __shared__ int n_coll_s;
+    __shared__ int n_coll_s[2];        // colliding entities among the first / the second wave's 64
     // the colliding entities packed for the contact loops: (x, y, size) of coll_idx[k]
     __shared__ __attribute__((aligned(16))) T CP[MAX_E][4];
 
@@ -92,19 +92,22 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
             Vel[lane].y = vel_g[b * (2 * A) + 2 * lane + 1];
         }
     }
-    if (lane == 0) {
-        int n = 0;
-        for (int e = 0; e < E; ++e)
-            if (tb->collide[e]) coll_idx[n++] = e;
-        n_coll_s = n;
-    }
+    // The list of colliding entities, ascending.  Thread e speaks for entity e (NT == MAX_E): a wave's ballot ranks
+    // its entities, and the second wave's start where the first wave's count ends.  (One thread walking the table
+    // entity by entity took a fifth of a single step's launch.)
+    static_assert(NT == MAX_E && NT == 128, "one thread per entity, two waves");
+    const bool listed = lane < E && tb->collide[lane] != 0;
+    const unsigned long long wave_listed = __ballot(listed);
+    if ((lane & 63) == 0) n_coll_s[lane >> 6] = __popcll(wave_listed);
     __syncthreads();
-    const int n_coll = n_coll_s;
+    const int first_wave_count = n_coll_s[0];
+    const int n_coll = first_wave_count + n_coll_s[1];
+    const int list_pos = (lane < 64 ? 0 : first_wave_count) + __popcll(wave_listed & ((1ull << (lane & 63)) - 1ull));
+    if (listed) coll_idx[list_pos] = lane;
+    __syncthreads();
     const bool is_agent = lane < A;
     const int me = is_agent ? lane : 0;
-    int my_rank = -1;                   // position of this agent in the list of colliding entities
-    for (int k = 0; k < n_coll; ++k)
-        if (is_agent && coll_idx[k] == me) my_rank = k;
+    const int my_rank = (is_agent && listed) ? list_pos : -1;       // position of this agent in the list of colliding entities
     for (int k = lane; k < n_coll; k += NT) {
         const int j = coll_idx[k];
         CP[k][0] = P[j].x; CP[k][1] = P[j].y; CP[k][2] = size_s[j];
