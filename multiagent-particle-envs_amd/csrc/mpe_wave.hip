@@ -276,6 +276,13 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
 
         if (EPI == EPI_SPREAD) {
             bool finished = false;
+            // The observation needs the new positions, not the rewards: in a launch of one step every other world
+            // emits it before its rewards, so that one world's rows leave while its neighbour on the CU runs the reward
+            // loops (worlds launched together are in step, and one step gives them no time to drift apart: 38.3 ->
+            // 34.8 us at 64/64 x 2 048 worlds; a 25-step launch gains nothing from it).  Not under mpe_step_auto,
+            // whose time-limit reset must come between the rewards and the observation.
+            const bool obs_first = n_steps == 1 && au.step_count == nullptr && (blockIdx.x & 1u) != 0;
+            if (obs_first) emit_obs(obs_g + row * (long long)(A * OD));
             if (MODE != WMODE_OBSERVE || rew_g != nullptr) {
                 // ---- reward() :83-108 and benchmark_data() :58-74 ----
                 // the second wave takes the landmark minima while the agents' wave counts collisions
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                     repack();
                 }
             }
-            emit_obs(obs_g + row * (long long)(A * OD));
+            if (!obs_first) emit_obs(obs_g + row * (long long)(A * OD));
         }
     }
 
