@@ -125,9 +125,12 @@ def stored_valu(key):
 #                   env-step only actions are read and obs, rewards, done written.
 #   episode launch: as rollout, but the initial state is drawn on the device, not read, and the
 #                   observation of the reset state (what env.reset() returns) is written once per episode.
-def algorithmic_bytes(A, L, n_act, obs_total, s, steps_per_launch, reads_state=True, reset_obs=False):
-    state_rd = (4 * A * s + 2 * L * s) if reads_state else 0
-    state_wr = 4 * A * s
+#   consensus keeps ten past states per agent as state (hist_rows = 240 values per env): a launch that starts from
+#   a given state reads them all and every single step writes the newest slot (4A values); an episode launch reads
+#   none and keeps only the last slots, which are not counted.
+def algorithmic_bytes(A, L, n_act, obs_total, s, steps_per_launch, reads_state=True, reset_obs=False, hist_rows=0):
+    state_rd = (4 * A * s + 2 * L * s + hist_rows * s) if reads_state else 0
+    state_wr = 4 * A * s + (4 * A * s if (hist_rows and reads_state) else 0)
     per_step = 4 * n_act + obs_total * s + A * s + 1
     return per_step + (state_rd + state_wr + (obs_total * s if reset_obs else 0)) / float(steps_per_launch)
 
@@ -444,7 +447,7 @@ def main():
     lo = env.layout
     # an episode's state write-back is once per launch; every episode of a launch is counted as if it wrote it
     bytes_env_step = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, EPISODE if args.mode == "rollout" else 1,
-                                       reads_state=args.mode != "rollout", reset_obs=args.mode == "rollout")
+                                       reads_state=args.mode != "rollout", reset_obs=args.mode == "rollout", hist_rows=lo.n_hist_rows)
     bytes_launch = bytes_env_step * B * avg_steps
     achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
 
@@ -455,7 +458,7 @@ def main():
         run(STEP_MODE_WARMUP, "graph", False)
         dt2, _ = timed(STEP_MODE_STEPS, "graph", True)
         k2 = event_average() or dt2 * 1e3 / STEP_MODE_STEPS
-        b2 = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, 1) * B
+        b2 = algorithmic_bytes(A, env.n_landmarks, n_act, lo.obs_total, s, 1, hist_rows=lo.n_hist_rows) * B
         step_mode = {"value": world * B * A * STEP_MODE_STEPS / dt2, "unit": "agent-steps/s", "steps": STEP_MODE_STEPS,
                      "ms_per_step": dt2 * 1e3 / STEP_MODE_STEPS,
                      "launch": "mpe_step, 1 step/launch, %d launches per hipGraph replay" % EPISODE, "launch_ms_hip_events": k2,

@@ -52,6 +52,10 @@ def test_algorithmic_bytes_match_the_survey_figures():
     assert abs(bench.algorithmic_bytes(3, 3, 3, 42, 4, 25, reads_state=False, reset_obs=True) - 201.64) < 1e-9
     assert bench.algorithmic_bytes(4, 2, 4, 62, 4, 1) == 425                 # simple_tag
     assert bench.algorithmic_bytes(64, 64, 64, 64 * 258, 4, 1) == 69121     # simple_spread 64/64
+    # consensus: a single step also reads the ten-slot history (240 values) and writes the newest slot (24 values) ...
+    assert bench.algorithmic_bytes(6, 0, 6, 480, 4, 1, hist_rows=240) == 2161 + 960 + 96
+    # ... an episode launch reads no state at all
+    assert abs(bench.algorithmic_bytes(6, 0, 6, 480, 4, 25, reads_state=False, reset_obs=True, hist_rows=240) - 2049.64) < 1e-9
 
 
 def test_stored_traffic_is_refused_for_another_build(tmp_path, monkeypatch):
