@@ -199,6 +199,17 @@ int mpe_layout(const MpeHandle* h, MpeLayout* out);
 const char* mpe_last_error(const MpeHandle* h);
 
 /*
+ * The position of the handle's first env in the whole job's env index (0 unless set).  The reference seeds env k
+ * of a vectorised run from its global position (multiagent/backup/mappo.py:97 `env.seed(seed + subrank)`, :113
+ * `seed + 10000 * mpi_rank`); here every on-device draw -- the reset distributions of mpe_reset / mpe_episode(s) /
+ * mpe_step_auto, the respawn streams of simple_predator_prey and collector, the generator of mpe_set_noise -- is
+ * keyed by env_base + b for env b of the handle.  A batch sharded over several handles (one per GPU, shard g with
+ * env_base = first env of the shard) therefore draws, bit for bit, the worlds of the unsharded batch under the same
+ * seed.  Buffers stay indexed by the local b.  env_base < 2^48.
+ */
+int mpe_set_env_base(MpeHandle* h, uint64_t env_base);
+
+/*
  * MultiAgentEnv.step (environment.py:83-115) for every env of the batch:
  *   _set_action (environment.py:155-206, discrete int input) ->
  *   World.step (core.py:142-158: apply_action_force :161-167, apply_environment_force :170-181 with
@@ -270,7 +281,7 @@ int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_
 /*
  * Where a world with Agent.u_noise / Agent.c_noise (MpeSpec.u_noise / c_noise; no built-in scenario sets them)
  * takes its standard-normal draws, for which the reference calls np.random.randn (core.py:165,211):
- *   draws == NULL  the device's counter-based generator keyed by (seed, env index, step number, agent); the step
+ *   draws == NULL  the device's counter-based generator keyed by (seed, env_base + env index, step number, agent); the step
  *                  number counts the steps the handle has run since this call (every mpe_step / mpe_step_auto
  *                  adds 1, a rollout or episode launch its n_steps), so a sequence of launches never reuses a draw
  *   draws != NULL  for the NEXT stepping launch only: T[n_steps][B][stride] device array of the draws themselves,
@@ -282,6 +293,14 @@ int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_
  * the forces as given.  MPE_ERR_INVALID for a world without noise levels.
  */
 int mpe_set_noise(MpeHandle* h, uint64_t seed, const void* draws);
+
+/*
+ * The position of the handle's noise generator, for a checkpoint: set == 0 reads (seed, number of steps run since
+ * mpe_set_noise) into *seed / *step, set != 0 puts the generator there (and drops a pending draw array), so that a
+ * resumed batch continues the stream it left.  Like the generator itself it has no counterpart in the reference,
+ * whose noise comes from numpy's global generator (core.py:165,211).
+ */
+int mpe_noise_state(MpeHandle* h, int set, uint64_t* seed, uint64_t* step);
 
 /*
  * Scenario.post_step alone (simple_predator_prey.py:83-107, collector.py:84-110), what MultiAgentEnv.step
@@ -309,8 +328,8 @@ int mpe_observe(MpeHandle* h, const void* pos, const void* vel, const void* comm
  * velocity and comm; the aux landmark indices (goal of simple_adversary.py:41-45,
  * simple_push.py:40-42, simple_speaker_listener.py:40; both goal_b of simple_reference.py:33-35; goal
  * and key of simple_crypto.py:61-63) uniform over the landmarks.
- * Draws come from a counter-based generator keyed by (seed, env index, episode); they follow the
- * reference's distributions, not numpy's Mersenne-Twister stream.
+ * Draws come from a counter-based generator keyed by (seed, env_base + env index, episode), env_base from
+ * mpe_set_env_base; they follow the reference's distributions, not numpy's Mersenne-Twister stream.
  */
 int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask, void* pos,
               void* vel, void* comm, int32_t* aux, mpe_stream_t stream);
@@ -340,6 +359,11 @@ int mpe_world_step(MpeHandle* h, const void* u, const void* c, void* pos, void* 
  * hipFree or host allocation; errors are reported by mpe_last_error(NULL).  All calls on one GPU
  * share that GPU's array: calls that overlap in time on one GPU (different streams or threads)
  * race for it; calls on one stream, or otherwise ordered, are safe.
+ * Set-up: the array's device address is looked up once per device, by the first mpe_create on that device or by the
+ * first call of this entry point there.  That lookup must not happen under stream capture: a first call on a device
+ * that comes while `stream` is capturing (and no mpe_create has run for the device) is refused with MPE_ERR_INVALID
+ * before anything is enqueued -- the capture stays valid -- so make one call outside capture, or create any handle
+ * on the device, before capturing.
  */
 #define MPE_STATIC_SCRATCH_BYTES 8192
 int mpe_world_step_static(const MpeSpec* spec, int64_t n_envs, int dtype, int device, const void* u, const void* c,

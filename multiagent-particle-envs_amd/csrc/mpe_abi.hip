@@ -21,6 +21,7 @@ struct MpeHandle {
     // Agent.u_noise / c_noise draws: generator key, steps run since mpe_set_noise, and the draw array of the next launch
     unsigned long long noise_seed, noise_step;
     const void* noise_draws;
+    unsigned long long env_base;    // global index of the handle's first env (mpe_set_env_base), 0 by default
     char err[512];
 };
 
@@ -325,6 +326,12 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
         return fail(nullptr, MPE_ERR_UNSUPPORTED, "mpe_create: no kernel for scenario %d with %d agents / %d landmarks", s.scenario, s.A, s.L);
     }
     h->layout.state_env_major = h->use_wave ? 1 : 0;
+    {
+        // the library's set-up on this device: the address of mpe_world_step_static's static array, so that a first
+        // call of that entry point may come under stream capture (a failure here is reported by that call, not this one)
+        DeviceScope scope(device);
+        if (scope.status == hipSuccess) (void)prepare_static_scratch(device);
+    }
     if (h->use_wave) {
         if (n_envs > 0x7fffffffLL) { delete h; return fail(nullptr, MPE_ERR_INVALID, "mpe_create: at most 2^31-1 envs for this scenario size"); }
         DevTable t;
@@ -362,8 +369,9 @@ const char* mpe_last_error(const MpeHandle* h) { return h ? h->err : g_create_er
 static int run(MpeHandle* h, int mode, const StepArgs& args, mpe_stream_t stream, const char* who) {
     if (!h) return MPE_ERR_INVALID;
     StepArgs a = args;
+    a.env_base = a.reset.env_base = a.au.env_base = h->env_base;
     if (mode != 2 && h->spec.any_noise()) {
-        a.noise = NoiseArgs{1, h->spec.noise_stride(), h->noise_draws, h->noise_seed, h->noise_step};
+        a.noise = NoiseArgs{1, h->spec.noise_stride(), h->noise_draws, h->noise_seed, h->noise_step, h->env_base};
         if (((uintptr_t)h->noise_draws & (h->dtype == MPE_F64 ? 7u : 3u)) != 0) return fail(h, MPE_ERR_INVALID, "%s: misaligned noise draws", who);
     }
     if (h->spec.scenario == MPE_SCN_NONE) return fail(h, MPE_ERR_INVALID, "%s: handle was created with MPE_SCN_NONE; use mpe_world_step", who);
@@ -400,6 +408,13 @@ static int run(MpeHandle* h, int mode, const StepArgs& args, mpe_stream_t stream
     return MPE_OK;
 }
 
+int mpe_set_env_base(MpeHandle* h, uint64_t env_base) {
+    if (!h) return MPE_ERR_INVALID;
+    if (env_base > 0xffffffffffffull) return fail(h, MPE_ERR_INVALID, "mpe_set_env_base: env_base must be below 2^48");
+    h->env_base = env_base;
+    return MPE_OK;
+}
+
 int mpe_set_noise(MpeHandle* h, uint64_t seed, const void* draws) {
     if (!h) return MPE_ERR_INVALID;
     if (!h->spec.any_noise()) return fail(h, MPE_ERR_INVALID, "mpe_set_noise: no agent of this world has u_noise or c_noise");
@@ -407,6 +422,20 @@ int mpe_set_noise(MpeHandle* h, uint64_t seed, const void* draws) {
     h->noise_seed = seed;
     h->noise_step = 0;
     h->noise_draws = draws;
+    return MPE_OK;
+}
+
+int mpe_noise_state(MpeHandle* h, int set, uint64_t* seed, uint64_t* step) {
+    if (!h) return MPE_ERR_INVALID;
+    if (!seed || !step) return fail(h, MPE_ERR_INVALID, "mpe_noise_state: seed and step must not be NULL");
+    if (set) {
+        h->noise_seed = *seed;
+        h->noise_step = *step;
+        h->noise_draws = nullptr;
+    } else {
+        *seed = h->noise_seed;
+        *step = h->noise_step;
+    }
     return MPE_OK;
 }
 
@@ -480,6 +509,7 @@ int mpe_post_step(MpeHandle* h, void* pos, int32_t* aux, mpe_stream_t stream) {
     StepArgs a{};
     a.pos = pos;
     a.aux = aux;
+    a.env_base = h->env_base;
     e = launch_small(h->spec, h->layout.n_envs, h->dtype, 3, a, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, "mpe_post_step");
     return MPE_OK;
@@ -497,8 +527,8 @@ int mpe_reset(MpeHandle* h, uint64_t seed, uint64_t episode, const uint8_t* mask
     hipError_t e = scope.status;
     if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
     e = h->spec.scenario == MPE_SCN_CONSENSUS
-            ? launch_consensus_reset(h->spec, h->layout.n_envs, h->dtype, seed, episode, mask, pos, vel, comm, aux, (hipStream_t)stream)
-            : launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, h->use_wave, seed, episode, mask, pos, vel, comm, aux, (hipStream_t)stream);
+            ? launch_consensus_reset(h->spec, h->layout.n_envs, h->dtype, seed, episode, h->env_base, mask, pos, vel, comm, aux, (hipStream_t)stream)
+            : launch_reset(h->spec, h->layout.n_envs, h->dtype, comm_rows, h->use_wave, seed, episode, h->env_base, mask, pos, vel, comm, aux, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(h, e, "mpe_reset");
     return MPE_OK;
 }
@@ -535,6 +565,10 @@ int mpe_world_step_static(const MpeSpec* spec, int64_t n_envs, int dtype, int de
     hipError_t e = scope.status;
     if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
     e = launch_world_step_static(s, t, device, n_envs, dtype, u, c, pos, vel, comm, rows, (hipStream_t)stream);
+    if (e == hipErrorStreamCaptureUnsupported)
+        return fail(nullptr, MPE_ERR_INVALID, "mpe_world_step_static: the first call on device %d came while its stream is being captured, and the "
+                    "static array's address is not known yet; make one call outside capture first (mpe_create on the device also resolves it). "
+                    "Nothing was enqueued", device);
     if (e != hipSuccess) return hip_fail(nullptr, e, "mpe_world_step_static");
     return MPE_OK;
 }

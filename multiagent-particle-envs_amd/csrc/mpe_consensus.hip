@@ -346,7 +346,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
                     }
                 }
                 // Scenario.reset_world with the next episode's draws for the worlds that finished; obs below is the fresh one
-                reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0}, finished, 0);
+                reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0, au.env_base}, finished, 0);
             }
             if (valid) {
                 rew_g[row * CA + tid] = out;        // 32 worlds x 6 rewards: six whole lines
@@ -417,7 +417,9 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
                 T* const dst = (c < 2) ? pos_g : vel_g;
                 if (wj < nvalid) dst[(long long)(2 * (r >> 2) + (c & 1)) * B + env0 + wj] = xch[r * XS + wj];
             }
-            if (tid < nvalid) aux_g[env0 + tid] = head;
+            // every world's own head: a time-limit reset inside the launch (mpe_step_auto) puts the worlds it resets
+            // back to slot 0 while their neighbours advance, so the heads may differ by now
+            if (valid && a == 0) aux_g[b] = head;
         } else if (valid) {
             pos_g[(long long)(2 * a) * B + b] = pos.x; pos_g[(long long)(2 * a + 1) * B + b] = pos.y;
             vel_g[(long long)(2 * a) * B + b] = vel.x; vel_g[(long long)(2 * a + 1) * B + b] = vel.y;
@@ -484,8 +486,8 @@ hipError_t launch_consensus(const HostSpec& s, long long B, int dtype, int mode,
 }
 
 hipError_t launch_consensus_reset(const HostSpec& s, long long B, int dtype, unsigned long long seed, unsigned long long episode,
-                                  const uint8_t* mask, void* pos, void* vel, void* hist, int32_t* aux, hipStream_t st) {
-    const ResetArgs rs{1, seed, episode, 1.0};
+                                  unsigned long long env_base, const uint8_t* mask, void* pos, void* vel, void* hist, int32_t* aux, hipStream_t st) {
+    const ResetArgs rs{1, seed, episode, 1.0, 0, env_base};
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
     if (dtype == MPE_F64)
         hipLaunchKernelGGL(consensus_reset_kernel<double>, grid, block, 0, st, B, rs, mask, (double*)pos, (double*)vel, (double*)hist, aux);

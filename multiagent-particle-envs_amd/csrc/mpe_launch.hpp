@@ -66,6 +66,7 @@ struct ResetArgs {
     unsigned long long seed, episode;
     double landmark_lim;      // landmarks ~ U(-lim, lim)^2; agents always U(-1, 1)^2
     int period;               // > 0: the launch holds several episodes, reset again every `period` steps (episode + 1, + 2, ...)
+    unsigned long long env_base;      // global index of the batch's first env: env b draws as env env_base + b of an unsharded batch
 };
 
 // Episode bookkeeping of mpe_step_auto (all pointers NULL = plain mpe_step).
@@ -77,6 +78,7 @@ struct AutoArgs {
     int max_steps;
     unsigned long long seed;
     double landmark_lim;
+    unsigned long long env_base;      // as ResetArgs::env_base
 };
 
 // Where the standard-normal draws of Agent.u_noise / Agent.c_noise come from (mpe_math.hpp: noise_pair).
@@ -85,6 +87,7 @@ struct NoiseArgs {
     int stride;                         // values per (step, env) row of `draws`: 2A + S * dim_c, rounded up to even
     const void* draws;                  // T[n_steps][B][stride]: [2i + d] force noise of agent i, [2A + j] comm value j; or NULL
     unsigned long long seed, step0;     // generator key and the step number of the launch's first step
+    unsigned long long env_base;        // the generator's env counter is env_base + b (the draws array is indexed by b)
 };
 
 struct StepArgs {
@@ -99,6 +102,7 @@ struct StepArgs {
     int32_t* aux;             // [n_aux][B] per-episode scenario state (landmark indices), or NULL
     void* obs0;               // episode launches: T[n_episodes][B][obs_total] observation of each reset state, or NULL
     NoiseArgs noise;          // enabled only for worlds with u_noise / c_noise
+    unsigned long long env_base;      // global index of the batch's first env (mpe_set_env_base): keys every on-device draw
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112
@@ -117,12 +121,13 @@ hipError_t launch_small(const HostSpec& s, long long n_envs, int dtype, int mode
 namespace mpe {
 // on-device reset_world (mpe_reset.hip); env_major selects the state layout
 hipError_t launch_reset(const HostSpec& s, long long n_envs, int dtype, int comm_rows, bool env_major, unsigned long long seed,
-                        unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, int32_t* aux, hipStream_t st);
+                        unsigned long long episode, unsigned long long env_base, const uint8_t* mask, void* pos, void* vel, void* comm, int32_t* aux,
+                        hipStream_t st);
 
 // consensus (mpe_consensus.hip): a.comm is the history ring, a.aux its head; mode: 0 step, 1 rollout, 2 observe
 hipError_t launch_consensus(const HostSpec& s, long long n_envs, int dtype, int mode, const StepArgs& a, hipStream_t st);
 hipError_t launch_consensus_reset(const HostSpec& s, long long n_envs, int dtype, unsigned long long seed, unsigned long long episode,
-                                  const uint8_t* mask, void* pos, void* vel, void* hist, int32_t* aux, hipStream_t st);
+                                  unsigned long long env_base, const uint8_t* mask, void* pos, void* vel, void* hist, int32_t* aux, hipStream_t st);
 
 // advantage scan (mpe_gae.hip)
 hipError_t launch_gae(int mode, long long n_envs, int n_agents, int n_steps, const float* rew, const float* val, const uint8_t* dones,
@@ -137,4 +142,6 @@ hipError_t launch_world_step(const HostSpec& s, const DevTable* table, long long
 // allocation (mpe_wave.hip); `device` must be current
 hipError_t launch_world_step_static(const HostSpec& s, const DevTable& table, int device, long long n_envs, int dtype, const void* u, const void* c,
                                     void* pos, void* vel, void* comm, int n_speak_rows, hipStream_t st);
+// resolves the static array's address on `device` (which must be current) ahead of the first mpe_world_step_static
+hipError_t prepare_static_scratch(int device);
 }  // namespace mpe

@@ -263,14 +263,15 @@ struct Philox {
 };
 
 // Position of entity `e` of world `b` in episode rs.episode: the two coordinates come from the
-// Philox block with key = seed and counter = (b, episode * 256 + e), mapped like numpy's
+// Philox block with key = seed and counter = (rs.env_base + b, episode * 256 + e) -- the world's index in
+// the whole job, so that a batch sharded over several handles draws the worlds of the unsharded one -- mapped like numpy's
 // uniform(low, high) = low + (high - low) * random_sample().  Shared by reset_kernel and the
 // fused reset of the rollout kernels so both produce the same worlds.  `attempt` > 0 gives the
 // redraws of a placement that is repeated until it is free (bits 48.. of the counter's high word).
 template <class RS>
 __host__ __device__ inline V2<double> reset_draw(const RS& rs, unsigned long long b, int e, bool is_agent, int attempt = 0) {
     uint32_t r[4];
-    Philox::block(rs.seed, b, rs.episode * 256ull + (unsigned long long)e + ((unsigned long long)attempt << 48), r);
+    Philox::block(rs.seed, rs.env_base + b, rs.episode * 256ull + (unsigned long long)e + ((unsigned long long)attempt << 48), r);
     const double lim = is_agent ? 1.0 : rs.landmark_lim;
     V2<double> d;
     d.x = -lim + (lim + lim) * Philox::u01(r[0], r[1]);
@@ -286,7 +287,7 @@ __host__ __device__ inline V2<double> reset_draw(const RS& rs, unsigned long lon
 template <class RS>
 __host__ __device__ inline int reset_aux(const RS& rs, unsigned long long b, int k, int n_landmarks) {
     uint32_t r[4];
-    Philox::block(rs.seed, b, rs.episode * 256ull + 255ull, r);
+    Philox::block(rs.seed, rs.env_base + b, rs.episode * 256ull + 255ull, r);
     return (int)(((uint64_t)r[k] * (uint64_t)n_landmarks) >> 32);
 }
 
@@ -295,7 +296,7 @@ __host__ __device__ inline int reset_aux(const RS& rs, unsigned long long b, int
 template <class RS>
 __host__ __device__ inline int reset_stream_key(const RS& rs, unsigned long long b, int w = 0) {
     uint32_t r[4];
-    Philox::block(rs.seed, b, rs.episode * 256ull + 255ull, r);
+    Philox::block(rs.seed, rs.env_base + b, rs.episode * 256ull + 255ull, r);
     return (int)r[w];
 }
 
@@ -310,7 +311,7 @@ __device__ __noinline__ inline PhiloxWords philox_block_call(uint64_t key, uint6
     return PhiloxWords{out[0], out[1], out[2], out[3]};
 }
 
-// n-th respawn position of world `b`, U(-lim, lim)^2, from the world's own stream key.  *spare
+// n-th respawn position of world `b` (its index in the whole job), U(-lim, lim)^2, from the world's own stream key.  *spare
 // receives the low 5 bits of the block's first word, which the position does not use.
 __device__ inline V2<double> respawn_draw(int key, unsigned long long b, int n, double lim, int* spare = nullptr) {
     const PhiloxWords r = philox_block_call(0x5eed5eed00000000ull | (uint32_t)key, b, (unsigned long long)(uint32_t)n);
@@ -350,7 +351,7 @@ __device__ __forceinline__ V2<T> noise_pair(const NoiseArgs& nz, long long t, lo
         const T* d = static_cast<const T*>(nz.draws) + ((t * B + b) * (long long)nz.stride + 2 * k);
         z.x = d[0]; z.y = d[1];
     } else {
-        const V2<double> n = normal_pair_call(nz.seed, (unsigned long long)b, (nz.step0 + (unsigned long long)t) * 256ull + (unsigned long long)k);
+        const V2<double> n = normal_pair_call(nz.seed, nz.env_base + (unsigned long long)b, (nz.step0 + (unsigned long long)t) * 256ull + (unsigned long long)k);
         z.x = (T)n.x; z.y = (T)n.y;
     }
     return z;

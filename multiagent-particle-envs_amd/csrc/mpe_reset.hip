@@ -1,8 +1,9 @@
 // On-device Scenario.reset_world: fresh uniform positions, zero velocity and comm state, goal landmark.
 //
 // One lane per world.  Entity e of world b in episode n takes its two coordinates from the
-// Philox-4x32-10 block with key = seed and counter = (b, n * 256 + e), so a reset is reproducible
-// and independent of batch size, launch geometry and of which other worlds are reset with it.
+// Philox-4x32-10 block with key = seed and counter = (env_base + b, n * 256 + e), so a reset is reproducible
+// and independent of batch size, launch geometry, of which other worlds are reset with it and -- with env_base =
+// the global index of the batch's first env -- of how a job's worlds are sharded over handles and GPUs.
 #include "mpe_launch.hpp"
 #include "mpe_scenarios.hpp"
 
@@ -46,8 +47,9 @@ __global__ __launch_bounds__(256) void reset_kernel(long long B, int E, int A, i
 }
 
 hipError_t launch_reset(const HostSpec& s, long long B, int dtype, int comm_rows, bool env_major, unsigned long long seed,
-                        unsigned long long episode, const uint8_t* mask, void* pos, void* vel, void* comm, int32_t* aux, hipStream_t st) {
-    const ResetArgs rs{1, seed, episode, landmark_limit(s)};
+                        unsigned long long episode, unsigned long long env_base, const uint8_t* mask, void* pos, void* vel, void* comm, int32_t* aux,
+                        hipStream_t st) {
+    const ResetArgs rs{1, seed, episode, landmark_limit(s), 0, env_base};
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
     ResetSizes sizes = {};
     for (int e = 0; e < s.E() && e < 16; ++e) sizes.size_d[e] = s.size[e];

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                 if (finished) {       // Scenario.reset_world with the next episode's draws; obs below is the fresh one
                     const int epi = au.episode_count[b] + 1;
                     if (valid) au.episode_count[b] = epi;
-                    const ResetArgs nr{1, au.seed, (unsigned long long)epi, au.landmark_lim};
+                    const ResetArgs nr{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0, au.env_base};
                     draw_world(nr);
 #pragma unroll
                     for (int i = 0; i < A; ++i) { vel[i].x = T(0); vel[i].y = T(0); }
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
         }
         // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
         // reset starts its episode untouched
-        if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, (unsigned long long)b);
+        if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, p.env_base + (unsigned long long)b);
         __syncthreads();
         STAMP_T(41);
         if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) ObsTile::template flush<FULL>(tile_obs, obs_dst, lane, nvalid);
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64) void post_step_kernel(const SmallParams<T, Cfg:
     }
 #pragma unroll
     for (int k = 0; k < NX; ++k) aux[k] = aux_g[(long long)k * B + b];
-    Cfg::post_step(pos, aux, p, (unsigned long long)b);
+    Cfg::post_step(pos, aux, p, p.env_base + (unsigned long long)b);
 #pragma unroll
     for (int e = A; e < E; ++e) {
         pos_g[(long long)(2 * e) * B + b] = pos[e].x;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64) void post_step_kernel(const SmallParams<T, Cfg:
 
 // ------------------------------------------------------------------------------------------
 template <typename T, class Cfg>
-static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n_envs) {
+static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n_envs, unsigned long long env_base) {
     SmallParams<T, Cfg::E, Cfg::A> p;
     for (int e = 0; e < Cfg::E; ++e) p.size[e] = (T)s.size[e];
     for (int i = 0; i < Cfg::A; ++i) {
@@ -730,6 +730,7 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     p.contact_force = (T)s.contact_force;
     p.contact_margin = (T)s.contact_margin;
     p.n_envs = n_envs;
+    p.env_base = env_base;
     for (int e = 0; e < Cfg::E; ++e) p.size_d[e] = s.size[e];
     for (int i = 0; i < Cfg::A; ++i) { p.u_noise[i] = (T)s.u_noise[i]; p.c_noise[i] = (T)s.c_noise[i]; }
     for (int i = 0; i < Cfg::A; ++i) { p.force_scale[i] = (T)s.force_scale[i]; p.ghost[i] = s.ghost[i]; }
@@ -781,7 +782,7 @@ static void launch_mode(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, co
 
 template <typename T, class Cfg, bool CLAMP>
 static hipError_t launch_cfg(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
-    const auto p = make_params<T, Cfg>(s, B);
+    const auto p = make_params<T, Cfg>(s, B, a.env_base);
     const bool info = a.info_i != nullptr;
     switch (mode) {
         case MODE_STEP:
@@ -799,7 +800,7 @@ static hipError_t launch_cfg(const HostSpec& s, long long B, int mode, const Ste
 
 template <typename T, class Cfg>
 static hipError_t launch_post_step(const HostSpec& s, long long B, const StepArgs& a, hipStream_t st) {
-    const auto p = make_params<T, Cfg>(s, B);
+    const auto p = make_params<T, Cfg>(s, B, a.env_base);
     hipLaunchKernelGGL((post_step_kernel<T, Cfg>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, p, (T*)a.pos, a.aux);
     return hipGetLastError();
 }

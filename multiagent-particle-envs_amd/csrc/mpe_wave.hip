@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                     done_g[row] = finished ? 1 : 0;
                 }
                 if (finished) {     // Scenario.reset_world with the next episode's draws
-                    const ResetArgs nr{1, au.seed, (unsigned long long)epi, au.landmark_lim};
+                    const ResetArgs nr{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0, au.env_base};
                     draw_world(nr);
                     repack();
                 }
@@ -452,11 +452,19 @@ static void* g_scratch_ptr[SCRATCH_MAX_DEVICES];    // device address of `scratc
 static std::mutex g_scratch_mutex;
 
 // Address of the CURRENT device's copy of `scratch` (the caller has made `device` current).  In host code
-// the array's name is only a handle for this lookup, never a device address.
-static hipError_t scratch_address(int device, void** out) {
+// the array's name is only a handle for this lookup, never a device address.  The lookup itself
+// (hipGetSymbolAddress, which may load the code object on that device) is not something to do while `capturing`
+// stream is recording a graph: an address that is not known yet is then refused with
+// hipErrorStreamCaptureUnsupported, before anything touches the stream, so the caller's capture stays valid.
+static hipError_t scratch_address(int device, void** out, hipStream_t capturing = nullptr, bool check_capture = false) {
     if (device < 0 || device >= SCRATCH_MAX_DEVICES) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (g_scratch_ptr[device] == nullptr) {
+        if (check_capture && capturing != nullptr) {
+            hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(capturing, &status) == hipSuccess && status != hipStreamCaptureStatusNone)
+                return hipErrorStreamCaptureUnsupported;
+        }
         void* ptr = nullptr;
         const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
@@ -465,6 +473,13 @@ static hipError_t scratch_address(int device, void** out) {
     }
     *out = g_scratch_ptr[device];
     return hipSuccess;
+}
+
+// Set-up: resolves the CURRENT device's address of `scratch` ahead of use (mpe_create does this for its device), so
+// that a later mpe_world_step_static may be the first one and still run under stream capture.
+hipError_t prepare_static_scratch(int device) {
+    void* ptr = nullptr;
+    return scratch_address(device, &ptr);
 }
 
 // The table travels as kernel arguments (copied at launch, also under graph capture), a piece at a time:
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(256) void table_piece_kernel(uint32_t* __restrict__
 hipError_t launch_world_step_static(const HostSpec& s, const DevTable& table, int device, long long B, int dtype, const void* u, const void* c,
                                     void* pos, void* vel, void* comm, int n_speak_rows, hipStream_t st) {
     void* ptr = nullptr;
-    hipError_t e = scratch_address(device, &ptr);
+    hipError_t e = scratch_address(device, &ptr, st, true);
     if (e != hipSuccess) return e;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&table);
     const int total = (int)(sizeof(DevTable) / 4);

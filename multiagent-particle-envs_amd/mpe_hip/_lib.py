@@ -73,8 +73,12 @@ EXPORTS = {
     # (handle, pos, vel, comm, aux, obs, rew, info_i, info_f, stream)
     "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]),
     "mpe_post_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # (handle, env_base)
+    "mpe_set_env_base": (C.c_int, [C.c_void_p, C.c_uint64]),
     # (handle, seed, draws)
     "mpe_set_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    # (handle, set, seed*, step*)
+    "mpe_noise_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     # (handle, seed, episode, mask, pos, vel, comm, aux, stream)
     "mpe_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),

@@ -37,7 +37,7 @@ class BatchedEnv:
     """
 
     def __init__(self, scenario, n_envs, dtype=torch.float32, device="cuda:0", info=False, max_episode_steps=None, seed=0,
-                 scripted=None, **spec_kw):
+                 scripted=None, env_base=0, **spec_kw):
         self.spec = scenario if isinstance(scenario, WorldSpec) else make_spec(scenario, **spec_kw)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -53,6 +53,13 @@ class BatchedEnv:
         _lib.check(None, self._lib.mpe_create(C.byref(cspec), self.n_envs, _lib.MPE_F64 if dtype == torch.float64 else _lib.MPE_F32,
                                               dev_index, C.byref(h)))
         self._h = h
+        # Position of this batch's first env in the whole job's env index (a shard of a larger batch: rank r of G
+        # holds envs [r * B, (r + 1) * B) and passes env_base = r * B).  Every on-device draw is keyed by env_base + b,
+        # so the shards of a job draw exactly the worlds of the unsharded batch under the same seed (the reference
+        # seeds env k of a vectorised run by its global position, multiagent/backup/mappo.py:97,113).
+        self.env_base = int(env_base)
+        if self.env_base:
+            _lib.check(h, self._lib.mpe_set_env_base(h, self.env_base))
         lo = _lib.MpeLayout()
         _lib.check(h, self._lib.mpe_layout(h, C.byref(lo)))
         self.layout = lo
@@ -154,6 +161,10 @@ class BatchedEnv:
         the fresh observations like MultiAgentEnv.reset unless ``observe`` is False."""
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        if self.max_episode_steps is not None and mask is not None and self._auto_since_reset and int(seed) != self.seed:
+            # mpe_step_auto takes ONE seed for the whole batch: envs left out of this reset would otherwise draw their
+            # later automatic resets from a seed other than the one their episode numbering started under
+            raise ValueError("a masked reset under max_episode_steps keeps the batch's seed (%d); reset every env to change it" % self.seed)
         if self.max_episode_steps is not None and self._auto_since_reset:
             # automatic resets on the device have drawn episodes up to max(episode_count) of the seed: start
             # beyond them, so that no env replays a world it (or a neighbour) has already played
@@ -311,28 +322,58 @@ class BatchedEnv:
 
     _STATE_FIELDS = ("pos", "vel", "comm", "aux", "step_count", "episode_count", "ep_return", "last_return")
 
+    def _fingerprint(self):
+        """sha256 over everything a resume depends on besides the tensors: the world description (every spec array and
+        scalar), the time limit, the state layout and the batch's place in the job's env index."""
+        import dataclasses
+        import hashlib
+        h = hashlib.sha256()
+        for f in dataclasses.fields(self.spec):
+            v = getattr(self.spec, f.name)
+            h.update(f.name.encode() + b"=")
+            h.update(np.asarray(v, dtype=np.float64).tobytes() if isinstance(v, np.ndarray) else repr(v).encode())
+        h.update(repr((self.max_episode_steps, self.env_major, self.env_base)).encode())
+        return h.hexdigest()[:32]
+
+    def _noise_state(self, put=None):
+        seed, step = C.c_uint64(0 if put is None else put[0]), C.c_uint64(0 if put is None else put[1])
+        _lib.check(self._h, self._lib.mpe_noise_state(self._h, 0 if put is None else 1, C.byref(seed), C.byref(step)))
+        return int(seed.value), int(step.value)
+
     def state_dict(self):
         """Checkpoint of the batch: copies (on the device) of everything its future depends on -- positions,
         velocities, comm state or history ring, the scenarios' int state, the episode bookkeeping of
-        ``max_episode_steps`` -- plus the episode numbering of the resets.  ``load_state_dict`` on an env built with
-        the same arguments resumes bit for bit; the dict holds tensors and ints only (``torch.save`` takes it).  Not
-        included: the step number of the device's noise generator (call ``set_noise`` again after loading)."""
+        ``max_episode_steps``, the position of the device's noise generator -- plus the episode numbering of the
+        resets.  ``load_state_dict`` on an env built with the same arguments resumes bit for bit (an env built with
+        other sizes, noise levels, time limit or ``env_base`` is refused); the dict holds tensors, ints and strings
+        only (``torch.save`` takes it).  Draw arrays handed to ``set_noise`` for the next launch are not part of it."""
         return {"scenario": self.spec.name, "n_envs": self.n_envs, "dtype": str(self.dtype), "env_major": self.env_major,
                 "episode": self._episode, "seed": self.seed, "auto_since_reset": self._auto_since_reset,
+                "max_episode_steps": -1 if self.max_episode_steps is None else int(self.max_episode_steps),
+                "env_base": self.env_base, "fingerprint": self._fingerprint(), "noise": list(self._noise_state()),
                 "tensors": {k: getattr(self, k).clone() for k in self._STATE_FIELDS if getattr(self, k, None) is not None}}
 
     def load_state_dict(self, sd):
-        """Restore a ``state_dict`` taken from an env of the same scenario, size, dtype and bookkeeping."""
+        """Restore a ``state_dict`` taken from an env of the same scenario, world description, size, dtype, time
+        limit and ``env_base``."""
         have = [k for k in self._STATE_FIELDS if getattr(self, k, None) is not None]
         if (sd["scenario"], sd["n_envs"], sd["dtype"]) != (self.spec.name, self.n_envs, str(self.dtype)) or sorted(sd["tensors"]) != sorted(have):
             raise ValueError("checkpoint of %s x %d (%s, fields %s) does not fit this env: %s x %d (%s, fields %s)"
                              % (sd["scenario"], sd["n_envs"], sd["dtype"], sorted(sd["tensors"]), self.spec.name, self.n_envs, self.dtype, sorted(have)))
+        mine = {"max_episode_steps": -1 if self.max_episode_steps is None else int(self.max_episode_steps), "env_major": self.env_major,
+                "env_base": self.env_base, "fingerprint": self._fingerprint()}
+        for k, v in mine.items():
+            if k in sd and sd[k] != v:
+                raise ValueError("checkpoint was taken from an env with another %s (%r, this env: %r): it would not resume bit for bit"
+                                 % (k, sd[k], v))
         for k in have:
             t = sd["tensors"][k]
             if tuple(t.shape) != tuple(getattr(self, k).shape):
                 raise ValueError("checkpoint field %s has shape %s, expected %s" % (k, tuple(t.shape), tuple(getattr(self, k).shape)))
             getattr(self, k).copy_(t)
         self._episode, self.seed, self._auto_since_reset = int(sd["episode"]), int(sd["seed"]), bool(sd["auto_since_reset"])
+        if "noise" in sd:
+            self._noise_state(put=(int(sd["noise"][0]), int(sd["noise"][1])))
 
     def set_history(self, his_pos, his_vel):
         """consensus: the agents' last ten positions and velocities, [B, A, 10, 2] each, oldest first

@@ -107,7 +107,12 @@ class MultiAgentEnv:
         self.agents = self.world.policy_agents
         if len(action_n) != self.n:
             raise ValueError("expected %d actions, got %d" % (self.n, len(action_n)))
-        if self._scenario is not None:
+        # Agent.u_noise / c_noise (core.py:165,211; new_core.py:213): World.step draws them from numpy's global
+        # generator exactly where the reference does, which the fused launch cannot; a world with a noise level
+        # takes the unfused path (World.step on the device, callbacks through mpe_observe, post_step_callback below)
+        noisy = any(getattr(a, "u_noise", None) or getattr(a, "c_noise", None) for a in self.world.agents)
+        fused = self._scenario is not None and not noisy
+        if fused:
             obs_n, reward_n, info_list = self._fused_step(action_n)
             done_n = [False] * self.n
         else:
@@ -123,7 +128,7 @@ class MultiAgentEnv:
             info_n["r{}".format(i)] = r                                        # environment.py:100
         if self.shared_reward:
             reward_n = [np.sum(reward_n)] * self.n                             # environment.py:103-105
-        if self.post_step_callback is not None and not (self._scenario is not None and self._scenario.dynamic):
+        if self.post_step_callback is not None and not (fused and self._scenario.dynamic):
             self.post_step_callback(self.world, self.np_random)         # (the fused step of a dynamic scenario already applied it)
         return obs_n, reward_n, bool(any(done_n)), info_n                      # environment.py:110-115
 

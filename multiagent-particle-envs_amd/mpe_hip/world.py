@@ -180,16 +180,20 @@ class World:
         A = len(self.agents)
         u = np.zeros((1, 2 * A))
         c_rows = []
+        # motor / comm noise is drawn on the host exactly where and in the order the reference draws it from numpy's
+        # global generator: every movable agent's force noise first (apply_action_force, multiagent/core.py:163-166),
+        # the speakers' comm noise after it (update_agent_state, core.py:157-158,211).  new_core adds the force noise
+        # after scaling the action (new_core.py:213-214), so it is divided by the scale the kernel applies.
         for i, a in enumerate(self.agents):
-            # motor / comm noise is drawn on the host exactly where the reference draws it
-            # (multiagent/core.py:165,211); no in-scope scenario sets it.  new_core adds it after scaling
-            # the action (new_core.py:213-214), so it is divided by the scale the kernel applies.
-            un = np.random.randn(*a.action.u.shape) * a.u_noise if a.u_noise else 0.0
-            if self.new_core and a.u_noise:
-                un = un / (a.mass * a.accel if a.accel is not None else a.mass)
+            un = 0.0
+            if a.movable and a.u_noise:
+                un = np.random.randn(*np.shape(a.action.u)) * a.u_noise
+                if self.new_core:
+                    un = un / (a.mass * a.accel if a.accel is not None else a.mass)
             u[0, 2 * i:2 * i + 2] = np.asarray(a.action.u, dtype=np.float64) + un
+        for a in self.agents:
             if not a.silent:
-                cn = np.random.randn(*a.action.c.shape) * a.c_noise if a.c_noise else 0.0
+                cn = np.random.randn(*np.shape(a.action.c)) * a.c_noise if a.c_noise else 0.0
                 c_rows.append(np.asarray(a.action.c, dtype=np.float64) + cn)
         pos, vel, comm = self.pack_state()
         ow.put_state(pos, vel, comm)

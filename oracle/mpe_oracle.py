@@ -1028,10 +1028,11 @@ def device_noise_pair(seed, b, step, k):
     return rad * np.cos(2.0 * np.pi * u2), rad * np.sin(2.0 * np.pi * u2)
 
 
-def device_noise(spec: Spec, seed, step, B):
+def device_noise(spec: Spec, seed, step, B, env_base=0):
     """(noise_u [B, A, 2], noise_c [B, A, dim_c]) of step number `step`: pair i is agent i's force noise, the
-    comm values of the speakers follow in agent order, packed two to a pair from pair A on."""
-    b = np.arange(B, dtype=np.uint64)
+    comm values of the speakers follow in agent order, packed two to a pair from pair A on.  World b of the batch
+    draws as world env_base + b of the whole job."""
+    b = np.arange(B, dtype=np.uint64) + np.uint64(env_base)
     nu = np.zeros((B, spec.A, 2))
     nc = np.zeros((B, spec.A, spec.dim_c))
     for i in range(spec.A):
@@ -1054,11 +1055,11 @@ def device_respawn_draw(key, b, n, lim=0.95):
     return np.stack([-lim + (lim + lim) * _u01(r[..., 0], r[..., 1]), -lim + (lim + lim) * _u01(r[..., 2], r[..., 3])], axis=-1)
 
 
-def pp_device_reset(spec: Spec, seed, episode, B):
+def pp_device_reset(spec: Spec, seed, episode, B, env_base=0):
     """simple_predator_prey worlds as the device reset draws them (foods redrawn until clear of the
     barrier and the forests, simple_predator_prey.py:139-144).  Returns (pos [B, E, 2], stream key [B] int32)."""
     A = spec.A
-    b = np.arange(B, dtype=np.uint64)
+    b = np.arange(B, dtype=np.uint64) + np.uint64(env_base)
     pos = np.stack([device_reset_draw(seed, b, episode, e, 1.0 if e < A else 0.9) for e in range(spec.E)], axis=1)
     obst = [A, A + spec.forests[0], A + spec.forests[1]]
     for f in spec.food:
@@ -1285,10 +1286,10 @@ def device_respawn_type(key, b, n):
     return (r[..., 0] & np.uint32(1)).astype(np.int64)
 
 
-def collector_device_reset(spec: Spec, seed, episode, B):
+def collector_device_reset(spec: Spec, seed, episode, B, env_base=0):
     """collector worlds as the device reset draws them: agents U(-1,1)^2, treasures U(-0.95,0.95)^2, treasure
     types = bits 0..5 of word 1 of the aux block, stream key = word 0.  Returns (pos, ttype [B, 6], key [B])."""
-    b = np.arange(B, dtype=np.uint64)
+    b = np.arange(B, dtype=np.uint64) + np.uint64(env_base)
     pos = np.stack([device_reset_draw(seed, b, episode, e, 1.0 if e < spec.A else 0.95) for e in range(spec.E)], axis=1)
     w = device_aux_words(seed, b, episode)
     ttype = ((w[:, 1, None].astype(np.int64) >> np.arange(6)) & 1)

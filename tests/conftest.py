@@ -62,6 +62,43 @@ def decided_with_margin(size, pos, margin, ordered=()):
     return ok
 
 
+# ---- the float32 bar ----------------------------------------------------------------------------
+# Trajectories of the float32 kernels must stay within 1e-4 of the reference's float64 ones after a 25-step
+# episode: |got - ref| <= 1e-4 * max(1, |ref|), element by element.  Every comparison made through within_fp32_bar
+# also records the largest |got - ref| / max(1, |ref|) it saw under its label; at the end of a GPU session the
+# table goes to gpurun_out/fp32_margins.json (how far inside the bar each case really is).
+FP32_BAR = 1e-4
+FP32_MARGINS = {}
+
+
+def within_fp32_bar(got, ref, label, factor=1.0):
+    """True when every element of `got` is within factor * 1e-4 * max(1, |ref|) of `ref`; records the worst ratio.
+    `factor` > 1 is for derived quantities whose error is a known multiple of the state's (stated where it is used)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if got.size == 0:
+        return True
+    ratio = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    worst = float(ratio.max()) if not np.isnan(ratio).any() else float("nan")
+    rec = FP32_MARGINS.setdefault(label, {"worst_ratio": 0.0, "bar": FP32_BAR * factor, "elements": 0})
+    rec["worst_ratio"] = worst if np.isnan(worst) else max(rec["worst_ratio"], worst)
+    rec["elements"] += int(got.size)
+    return bool(worst <= FP32_BAR * factor)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not FP32_MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "fp32_margins.json"), "w") as f:
+            json.dump({"bar": "|got - ref| <= factor * 1e-4 * max(1, |ref|); worst_ratio = max |got - ref| / max(1, |ref|)",
+                       "cases": dict(sorted(FP32_MARGINS.items()))}, f, indent=1)
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden():
     return {k: load_golden(k) for k in GOLDEN_CASES}

@@ -54,6 +54,9 @@ def test_algorithmic_bytes_match_the_survey_figures():
     assert bench.algorithmic_bytes(64, 64, 64, 64 * 258, 4, 1) == 69121     # simple_spread 64/64
     # consensus: a single step also reads the ten-slot history (240 values) and writes the newest slot (24 values) ...
     assert bench.algorithmic_bytes(6, 0, 6, 480, 4, 1, hist_rows=240) == 2161 + 960 + 96
+    # mpe_step_auto: + step counter read and written, running return read and written, episode number read; per
+    # 25-step episode the finished return and the episode number written once
+    assert abs(bench.algorithmic_bytes(3, 3, 3, 42, 4, 1, auto_period=25) - (313 + 8 + 4 + 24 + 16 / 25)) < 1e-9
     # ... an episode launch reads no state at all
     assert abs(bench.algorithmic_bytes(6, 0, 6, 480, 4, 25, reads_state=False, reset_obs=True, hist_rows=240) - 2049.64) < 1e-9
 
@@ -106,6 +109,10 @@ def test_gpus_2_launches_its_own_ranks():
     assert out["shards"] == [[0, 1000], [1000, 2000]]   # env-index shards tile the global batch in rank order
     assert out["stats"]["episodes"] == 2000.0 and out["stats"]["return_agent0"] == -float(sum(range(2000)))
     assert out["plan"]["timed_steps"] == 25000
+    # one seed on every rank; a rank's draws are keyed by its shard's place in the global env index
+    assert out["ranks"]["world_size"] == 2 and out["ranks"]["backend"] == "gloo"
+    assert [(r["rank"], r["env_base"], r["envs"]) for r in out["ranks"]["ranks"]] == [(0, 0, 1000), (1, 1000, 1000)]
+    assert len({r["seed"] for r in out["ranks"]["ranks"]}) == 1
 
 
 def test_a_failing_rank_ends_the_launch():

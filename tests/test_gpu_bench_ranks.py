@@ -28,9 +28,14 @@ def _run(cmd):
 def _check(d):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["envs_per_gpu"] == 4096 and d["config"]["global_envs"] == 8192
-    assert d["steps"] == 500 and d["steps_requested"] == 20 and d["value"] > 0
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["timed_steps"] == 500 and d["value"] > 0
     # whole-job rate: both ranks' envs over the slower rank's time
-    assert abs(d["value"] - 8192 * 3 * d["steps"] / d["elapsed_s"]) <= 1e-6 * d["value"]
+    assert abs(d["value"] - 8192 * 3 * d["timed_steps"] / d["elapsed_s"]) <= 1e-6 * d["value"]
+    # what torch.distributed saw: two ranks, and ONE seed with each rank's shard keyed by its place in the env index
+    assert d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
+    assert [(r["rank"], r["env_base"], r["envs"]) for r in d["ranks"]["ranks"]] == [(0, 0, 4096), (1, 4096, 4096)]
+    assert len({r["seed"] for r in d["ranks"]["ranks"]}) == 1 and d["config"]["reset_seed"] == d["ranks"]["ranks"][0]["seed"]
+    assert d["configs"] is None and d["sustained"] is None      # one-GPU records
     assert d["cpu_baseline"] is None            # a one-GPU figure
     assert d["mean_episode_return_agent0"] < 0  # the statistics all-reduce ran over both shards
 

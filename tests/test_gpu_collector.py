@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
-from conftest import decided_with_margin, load_golden
+from conftest import decided_with_margin, load_golden, within_fp32_bar
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -21,6 +21,14 @@ CASE = "collector"
 def _close(a, b, rtol, atol):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.all(np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def _ok(dtype, got, ref, label, f32_factor=1.0, f64=(1e-9, 1e-12)):
+    """float64: within f64 = (rtol, atol) of the reference; float32: the stated bar |got - ref| <= f32_factor * 1e-4 *
+    max(1, |ref|), its observed margin recorded under `label`."""
+    if dtype == "float64":
+        return _close(got, ref, *f64)
+    return within_fp32_bar(got, ref, label, f32_factor)
 
 
 def _env(B, dtype, info=True, **kw):
@@ -59,8 +67,8 @@ def test_layout():
     assert env.obs_dims == list(g["obs_dims"]) and env.n_act == 8 and env.layout.n_aux == 3 and env.layout.n_info_i == 25
 
 
-@pytest.mark.parametrize("dtype,rtol,atol", [("float64", 1e-9, 1e-12), ("float32", 1e-4, 1e-4)])
-def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_teacher_forced_steps_match_reference(dtype):
     g = load_golden(CASE)
     T, B, A = g["actions"].shape
     env = _env(B, getattr(torch, dtype))
@@ -69,7 +77,7 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
     env.observe()
     exact = dtype == "float64"
     if exact:
-        assert _close(env.obs.cpu().numpy(), g["obs0"], rtol, atol)
+        assert _close(env.obs.cpu().numpy(), g["obs0"], 1e-9, 1e-12)
     spec = orc.make_spec(CASE)
     L = spec.L
     # nearest-first lists: every agent orders the other agents and the treasures by distance (collector.py:268-295)
@@ -80,8 +88,9 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
         env.set_state(pos, vel, goal=_aux(holding, ttype, alive))
         obs, rew, done, (info_i, _) = env.step(torch.as_tensor(g["actions"][t]))
         gp, gv, _ = env.get_state()
-        assert _close(gp[:, :A], g["pos"][t], rtol, atol), (t, np.abs(gp[:, :A] - g["pos"][t]).max())
-        assert _close(gv, g["vel"][t], rtol * 10, atol * 10), t
+        assert _ok(dtype, gp[:, :A], g["pos"][t], "collector single step:pos"), (t, np.abs(gp[:, :A] - g["pos"][t]).max())
+        # teacher-forced: a position within the bar bounds the velocity (position change / dt) to 10 times it
+        assert _ok(dtype, gv, g["vel"][t], "collector single step:vel", 10.0, (1e-8, 1e-11)), t
         ii = info_i.cpu().numpy()
         h2, t2, a2 = _unword(env.aux[0].cpu().numpy())
         # float32 may reorder two near-equidistant neighbours or flip a knife-edge contact of the fixture: the float64
@@ -91,8 +100,8 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
         after[:, :A] = g["pos"][t]
         sure = np.ones(B, bool) if exact else decided_with_margin(spec.size, after, 4e-4, ordered)
         sure_total += int(sure.sum())
-        assert _close(obs.cpu().numpy()[sure], g["obs"][t][sure], rtol, atol), (t, np.abs(obs.cpu().numpy() - g["obs"][t])[sure].max())
-        assert _close(rew.cpu().numpy()[sure], g["rew"][t][sure], rtol, 2 * atol), (t, np.abs(rew.cpu().numpy() - g["rew"][t])[sure].max())
+        assert _ok(dtype, obs.cpu().numpy()[sure], g["obs"][t][sure], "collector single step:obs"), (t, np.abs(obs.cpu().numpy() - g["obs"][t])[sure].max())
+        assert _ok(dtype, rew.cpu().numpy()[sure], g["rew"][t][sure], "collector single step:rew", 1.0, (1e-9, 2e-12)), (t, np.abs(rew.cpu().numpy() - g["rew"][t])[sure].max())
         assert np.array_equal(ii[sure, :3 * A].reshape(-1, A, 3), g["info"][t][sure]) and np.array_equal(ii[:, 3 * A], _word(holding, ttype, alive))
         assert np.array_equal(h2[sure], g["holding"][t][sure]) and np.array_equal(a2[sure], g["alive"][t][sure]), t
         keep = alive & a2 & sure[:, None]

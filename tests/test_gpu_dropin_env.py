@@ -72,6 +72,46 @@ def test_builtin_scenarios_replay_reference_episode(name, case):
         assert np.array_equal(env.world.agents[0].state.c, g["comm"][24, 30])
 
 
+def test_agent_noise_levels_use_numpys_global_generator_like_the_reference():
+    """Agent.u_noise / c_noise on a built-in scenario (core.py:165,211): the step leaves the fused launch and
+    World.step draws from np.random in the reference's order (every movable agent's force noise, then the
+    speakers' comm noise).  tests/golden/noise.npz was captured from the reference with the global generator
+    seeded 20240681 + 1 + b for env b, so seeding it alike must replay that trajectory."""
+    from make_env import make_env
+    g = load_golden("noise")
+    T, B, _ = g["actions"].shape
+    env = make_env("simple_world_comm")
+    assert env._scenario is not None                      # without noise levels this env steps fused
+    env.seed(0)
+    env.reset()
+    for a, un, cn in zip(env.world.agents, g["u_noise"], g["c_noise"]):
+        a.u_noise, a.c_noise = (float(un) if un else None), (float(cn) if cn else None)
+    for b in (0, 5):
+        for i, e in enumerate(env.world.entities):
+            e.state.p_pos = g["pos0"][b, i].copy()
+        for i, a in enumerate(env.world.agents):
+            a.state.p_vel = g["vel0"][b, i].copy()
+            a.state.c = np.zeros(env.world.dim_c)
+        np.random.seed(20240681 + 1 + b)
+        for t in range(T):
+            act = g["actions"][t, b]
+            obs_n, rew_n, done, _ = env.step([(int(act[0]), int(act[1]))] + [int(x) for x in act[2:]])
+            assert _close([a.state.p_pos for a in env.world.agents], g["pos"][t, b]), (b, t)
+            assert _close([a.state.p_vel for a in env.world.agents], g["vel"][t, b]), (b, t)
+            assert _close(env.world.agents[0].state.c, g["comm"][t, b]), (b, t)
+            assert _close(np.concatenate(obs_n), g["obs"][t, b]) and _close(rew_n, g["rew"][t, b]), (b, t)
+    # and the noise does change the step: the same start without it ends elsewhere
+    for a in env.world.agents:
+        a.u_noise = a.c_noise = None
+    for i, e in enumerate(env.world.entities):
+        e.state.p_pos = g["pos0"][0, i].copy()
+    for i, a in enumerate(env.world.agents):
+        a.state.p_vel = g["vel0"][0, i].copy()
+    act = g["actions"][0, 0]
+    env.step([(int(act[0]), int(act[1]))] + [int(x) for x in act[2:]])
+    assert not _close([a.state.p_pos for a in env.world.agents], g["pos"][0, 0], 1e-6, 1e-6)
+
+
 class _UserTagScenario:
     """A scenario written against the plugin contract only (Python callbacks reading
     agent.state / agent attributes), as a user of the reference would write it: simple_tag's

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
+from conftest import within_fp32_bar
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -75,7 +76,7 @@ def test_full_batch_episode(scn, kw, B, dtype):
         assert _close(out["obs"][-1].cpu().numpy()[idx], np.concatenate(o_obs, 1), tol, 1e-12).all()
         assert _close(out["rew"][-1].cpu().numpy()[idx], o_rew, 1e-9, 1e-12).all()
     elif A <= 6:
-        assert _close(pos1[idx], p, 1e-4, 1e-4).all() and _close(vel1[idx], v, 1e-4, 1e-4).all()
+        assert within_fp32_bar(pos1[idx], p, "full size %s:pos" % scn) and within_fp32_bar(vel1[idx], v, "full size %s:vel" % scn)
     else:
         # 64 overlapping agents: float32 trajectories decorrelate within an episode (chaotic contact
         # dynamics), so float32 is held to the oracle over the first step only
@@ -84,7 +85,7 @@ def test_full_batch_episode(scn, kw, B, dtype):
         small.step(actions[0][torch.as_tensor(idx, device="cuda:0")].contiguous())
         p1, v1, *_ = orc.env_step(spec, pos0[idx].astype(np.float64), vel0[idx].astype(np.float64), act[0])
         sp, sv, _ = small.get_state()
-        assert _close(sp, p1, 1e-4, 1e-4).all() and _close(sv, v1, 1e-4, 2e-4).all()
+        assert within_fp32_bar(sp, p1, "full size spread64 single step:pos") and within_fp32_bar(sv, v1, "full size spread64 single step:vel")
 
     # batch-composition independence + episode launch == step launches, bit for bit
     m = 1000 if A <= 6 else 37

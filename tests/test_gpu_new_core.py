@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
-from conftest import load_golden
+from conftest import load_golden, within_fp32_bar
 from test_oracle_golden import new_core_spec
 
 torch = pytest.importorskip("torch")
@@ -69,8 +69,10 @@ def test_fp32_new_core_single_steps_within_1e4():
         env.set_state(p0, v0)
         env.world_step(_u(g, t).reshape(B, 2 * A))
         pos, vel, _ = env.get_state()
-        assert _close(pos[:, :A], g["pos"][t], 1e-4, 1e-4), (t, np.abs(pos[:, :A] - g["pos"][t]).max())
-        assert _close(vel, g["vel"][t], 1e-3, 1e-3), t
+        assert within_fp32_bar(pos[:, :A], g["pos"][t], "new_core single step:pos"), (t, np.abs(pos[:, :A] - g["pos"][t]).max())
+        # a step's velocity change is force * dt / mass, its position change that times dt again: a teacher-forced
+        # position within the bar bounds the velocity only to 1 / dt = 10 times it
+        assert within_fp32_bar(vel, g["vel"][t], "new_core single step:vel", 10.0), t
 
 
 def test_core_handle_unchanged_by_the_new_fields():

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
-from conftest import load_golden
+from conftest import load_golden, within_fp32_bar
 from test_oracle_golden import noise_spec
 
 torch = pytest.importorskip("torch")
@@ -19,14 +19,22 @@ def _close(a, b, rtol, atol):
     return np.all(np.abs(a - b) <= atol + rtol * np.abs(b))
 
 
+def _ok(dtype, got, ref, label, f32_factor=1.0, f64=(1e-9, 1e-12)):
+    """float64: within f64 = (rtol, atol) of the reference; float32: the stated bar |got - ref| <= f32_factor * 1e-4 *
+    max(1, |ref|), its observed margin recorded under `label`."""
+    if dtype == "float64":
+        return _close(got, ref, *f64)
+    return within_fp32_bar(got, ref, label, f32_factor)
+
+
 def _noisy(name, u_noise, c_noise=None, **kw):
     import mpe_hip
     spec = mpe_hip.make_spec(name, **kw)
     return dataclasses.replace(spec, u_noise=np.asarray(u_noise, float), c_noise=None if c_noise is None else np.asarray(c_noise, float))
 
 
-@pytest.mark.parametrize("dtype,rtol,atol", [("float64", 1e-9, 1e-12), ("float32", 1e-4, 1e-4)])
-def test_reference_draws_give_the_reference_trajectory(dtype, rtol, atol):
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_reference_draws_give_the_reference_trajectory(dtype):
     import mpe_hip
     g = load_golden("noise")
     T, B, _ = g["actions"].shape
@@ -36,14 +44,14 @@ def test_reference_draws_give_the_reference_trajectory(dtype, rtol, atol):
         env.set_noise(noise_u=g["noise_u"][t], noise_c=g["noise_c"][t])
         obs, rew, _, _ = env.step(torch.as_tensor(g["actions"][t], dtype=torch.int32))
         pos, vel, comm = env.get_state()
-        assert _close(pos[:, :6], g["pos"][t], rtol, atol) and _close(vel, g["vel"][t], rtol, atol), t
-        assert _close(comm, g["comm"][t], rtol, atol) and _close(rew.cpu(), g["rew"][t], 10 * rtol, 10 * atol), t
-        assert _close(obs.cpu(), g["obs"][t], rtol, atol), t
+        assert _ok(dtype, pos[:, :6], g["pos"][t], "noise:pos") and _ok(dtype, vel, g["vel"][t], "noise:vel"), t
+        assert _ok(dtype, comm, g["comm"][t], "noise:comm") and _ok(dtype, rew.cpu(), g["rew"][t], "noise:rew", 1.0, (1e-8, 1e-11)), t
+        assert _ok(dtype, obs.cpu(), g["obs"][t], "noise:obs"), t
     # the same draws for all steps at once through a rollout launch
     env.set_state(g["pos0"], g["vel0"])
     env.set_noise(noise_u=g["noise_u"], noise_c=g["noise_c"])
     out = env.rollout(torch.as_tensor(g["actions"], dtype=torch.int32))
-    assert _close(out["obs"].cpu(), g["obs"], rtol, atol) and _close(env.get_state()[0][:, :6], g["pos"][-1], rtol, atol)
+    assert _ok(dtype, out["obs"].cpu(), g["obs"], "noise:obs") and _ok(dtype, env.get_state()[0][:, :6], g["pos"][-1], "noise:pos")
 
 
 def test_zero_noise_levels_change_nothing():

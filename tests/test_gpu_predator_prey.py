@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import mpe_oracle as orc
-from conftest import decided_with_margin, load_golden
+from conftest import decided_with_margin, load_golden, within_fp32_bar
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -20,6 +20,14 @@ CASE = "simple_predator_prey"
 def _close(a, b, rtol, atol):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.all(np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def _ok(dtype, got, ref, label, f32_factor=1.0, f64=(1e-9, 1e-12)):
+    """float64: within f64 = (rtol, atol) of the reference; float32: the stated bar |got - ref| <= f32_factor * 1e-4 *
+    max(1, |ref|), its observed margin recorded under `label`."""
+    if dtype == "float64":
+        return _close(got, ref, *f64)
+    return within_fp32_bar(got, ref, label, f32_factor)
 
 
 def _env(B, dtype, info=True, **kw):
@@ -53,15 +61,15 @@ def test_layout():
     assert env.obs_dims == list(g["obs_dims"]) and env.n_act == 7 and env.layout.n_aux == 3 and env.layout.n_info_i == 8
 
 
-@pytest.mark.parametrize("dtype,rtol,atol", [("float64", 1e-9, 1e-12), ("float32", 1e-4, 1e-4)])
-def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_teacher_forced_steps_match_reference(dtype):
     g = load_golden(CASE)
     T, B, A = g["actions"].shape
     env = _env(B, getattr(torch, dtype))
     pos, vel, alive, holding = _state_before(g, 0)
     env.set_state(pos, vel, goal=_aux(alive, holding))
     env.observe()
-    assert _close(env.obs.cpu().numpy(), g["obs0"], rtol, atol)
+    assert _ok(dtype, env.obs.cpu().numpy(), g["obs0"], "simple_predator_prey reset:obs")
     exact = dtype == "float64"
     spec = orc.make_spec(CASE)
     sure_total = 0
@@ -70,8 +78,9 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
         env.set_state(pos, vel, goal=_aux(alive, holding))
         obs, rew, done, (info_i, _) = env.step(torch.as_tensor(g["actions"][t]))
         gp, gv, _ = env.get_state()
-        assert _close(gp[:, :A], g["pos"][t], rtol, atol), (t, np.abs(gp[:, :A] - g["pos"][t]).max())
-        assert _close(gv, g["vel"][t], rtol * 10, atol * 10), t
+        assert _ok(dtype, gp[:, :A], g["pos"][t], "simple_predator_prey single step:pos"), (t, np.abs(gp[:, :A] - g["pos"][t]).max())
+        # teacher-forced: a position within the bar bounds the velocity (position change / dt) to 10 times it
+        assert _ok(dtype, gv, g["vel"][t], "simple_predator_prey single step:vel", 10.0, (1e-8, 1e-11)), t
         # float32 may flip a threshold test of the fixture's knife-edge placements (a distance within the float32
         # error of a contact radius): the float64 kernel must agree everywhere, the float32 kernel in every env whose
         # tests the reference's own positions decide with a 4e-4 margin (the position tolerance is 1e-4)
@@ -80,8 +89,8 @@ def test_teacher_forced_steps_match_reference(dtype, rtol, atol):
         after[:, :A] = g["pos"][t]
         sure = np.ones(B, bool) if exact else decided_with_margin(spec.size, after, 4e-4)
         sure_total += int(sure.sum())
-        assert _close(obs.cpu().numpy()[sure], g["obs"][t][sure], rtol, atol), t
-        assert _close(rew.cpu().numpy()[sure], g["rew"][t][sure], rtol, 2 * atol), t
+        assert _ok(dtype, obs.cpu().numpy()[sure], g["obs"][t][sure], "simple_predator_prey single step:obs"), t
+        assert _ok(dtype, rew.cpu().numpy()[sure], g["rew"][t][sure], "simple_predator_prey single step:rew", 1.0, (1e-9, 2e-12)), t
         assert np.array_equal(ii[sure, :A], g["collisions"][t][sure]) and np.array_equal(ii[:, A], _flags(alive, holding))
         assert np.array_equal(env.aux[0].cpu().numpy()[sure], _flags(g["alive"][t], g["holding"][t])[sure]), t
         assert not done.any()

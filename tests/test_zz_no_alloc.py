@@ -146,3 +146,78 @@ def test_static_entry_point_runs_under_graph_capture():
         env.world_step(ut, ct)
     torch.cuda.synchronize()
     assert torch.equal(pos, env.pos) and torch.equal(vel, env.vel) and torch.equal(comm, env.comm)
+
+
+_COLD_CAPTURE = r"""
+import ctypes as C, sys
+import numpy as np, torch
+sys.path.insert(0, %(pkg)r)
+from mpe_hip import _lib, physics_spec
+lib = _lib.load()
+A, L, B = 3, 2, 5
+spec = physics_spec(A, L, 4, [0.15, 0.1, 0.1, 0.2, 0.05], [1.0, 2.0, 1.0, 1.0, 1.0], [1, 1, 1, 1, 0], [5.0, 3.0, 4.0], [np.inf, 1.0, 1.3],
+                    [True, True, True])
+cspec, keep = spec.to_c()
+rng = np.random.RandomState(1)
+pos0 = torch.as_tensor(rng.uniform(-1, 1, (B, 2 * (A + L))), device="cuda")
+vel0 = torch.as_tensor(rng.uniform(-0.5, 0.5, (B, 2 * A)), device="cuda")
+u = torch.as_tensor(rng.uniform(-5, 5, (B, 2 * A)), device="cuda")
+pos, vel = pos0.clone(), vel0.clone()
+ptr = lambda t: C.c_void_p(t.data_ptr())
+call = lambda: lib.mpe_world_step_static(C.byref(cspec), B, _lib.MPE_F64, 0, ptr(u), None, ptr(pos), ptr(vel), None,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+# no handle was ever created and the entry point never ran: the static array's address is unknown on this device
+marker = torch.zeros(1, device="cuda")
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    rc_cold = call()
+    msg = lib.mpe_last_error(None).decode()
+    marker.add_(1)
+graph.replay()                      # a refused call enqueues nothing and leaves the capture valid: the rest of it replays
+torch.cuda.synchronize()
+assert float(marker) == 1.0
+assert rc_cold == -1 and "capture" in msg, (rc_cold, msg)
+assert torch.equal(pos, pos0) and torch.equal(vel, vel0)
+assert call() == 0                  # outside capture: resolves the address and steps
+torch.cuda.synchronize()
+want_pos, want_vel = pos.clone(), vel.clone()
+assert not torch.equal(want_pos, pos0)
+pos.copy_(pos0); vel.copy_(vel0)
+graph2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph2):
+    assert call() == 0              # now the same call is capturable
+graph2.replay()
+torch.cuda.synchronize()
+assert torch.equal(pos, want_pos) and torch.equal(vel, want_vel)
+print("COLD-CAPTURE-OK")
+"""
+
+
+def test_first_call_under_capture_is_refused_cleanly():
+    """A fresh process in which nothing has resolved the static array's address yet: the first call, made under
+    stream capture, must be refused (MPE_ERR_INVALID, nothing enqueued, the capture still valid); after one call
+    outside capture the same call captures and replays."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _COLD_CAPTURE % {"pkg": os.path.join(root, "multiagent-particle-envs_amd")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "COLD-CAPTURE-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_after_mpe_create_the_first_call_may_come_under_capture():
+    """mpe_create is the library's set-up on a device: it resolves the address, so a process whose first
+    mpe_world_step_static comes under capture works when any handle was created before."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (_COLD_CAPTURE % {"pkg": os.path.join(root, "multiagent-particle-envs_amd")}).replace(
+        "graph = torch.cuda.CUDAGraph()",
+        "import mpe_hip\nkeep_env = mpe_hip.BatchedEnv('simple_tag', 8, device='cuda:0')\ngraph = torch.cuda.CUDAGraph()", 1).replace(
+        'assert rc_cold == -1 and "capture" in msg, (rc_cold, msg)\nassert torch.equal(pos, pos0) and torch.equal(vel, vel0)',
+        'assert rc_cold == 0, (rc_cold, msg)\nassert not torch.equal(pos, pos0)\npos.copy_(pos0); vel.copy_(vel0)')
+    assert "keep_env" in code and "rc_cold == 0" in code
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "COLD-CAPTURE-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
