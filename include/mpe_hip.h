@@ -57,8 +57,9 @@
  *                            simple_speaker_listener, simple_reference) every agent's entry is the
  *                            sum of the agents' own rewards (environment.py:103-105); mpe_observe
  *                            writes the own rewards, which is what the reward callback returns
- *   done     uint8[B]        0: no in-scope scenario has a done callback (environment.py:143-146);
- *                            mpe_step_auto sets it to 1 on the step that reaches its time limit
+ *   done     uint8[B]        0: no in-scope scenario has a done callback (environment.py:143-146), unless the batch
+ *                            was given one with mpe_set_done_bound; mpe_step_auto also sets it to 1 on the step
+ *                            that reaches its time limit
  *   info_i   int32[B][n_info_i]   optional (NULL to skip), see mpe_layout
  *   info_f   T[B][n_info_f]       optional (NULL to skip)
  */
@@ -208,6 +209,18 @@ const char* mpe_last_error(const MpeHandle* h);
  * seed.  Buffers stay indexed by the local b.  env_base < 2^48.
  */
 int mpe_set_env_base(MpeHandle* h, uint64_t env_base);
+
+/*
+ * MultiAgentEnv's done_callback (environment.py:15-18,143-146) for a batch.  A Python callable cannot run in a kernel,
+ * so the batch carries the predicate the reference's own comment has in mind ("agents are allowed to go beyond the
+ * viewing screen", :142): done_callback(agent, world) = any(|agent.state.p_pos| > bound), an agent outside
+ * [-bound, bound]^2.  step combines the agents' values with any(done_n) (:98,110-113), evaluated on the state after
+ * World.step like the other callbacks.  With a bound set, mpe_step / mpe_rollout / mpe_episode(s) write that flag to
+ * done, and mpe_step_auto ends the episode on it exactly as on its time limit (done = 1, returns closed, on-device
+ * reset; what the runner does on a done env, backup/runner_old.py:56).  bound <= 0 or +inf switches it off (the
+ * default: done_callback=None, done always 0).  A NaN coordinate compares false, as in numpy.
+ */
+int mpe_set_done_bound(MpeHandle* h, double bound);
 
 /*
  * MultiAgentEnv.step (environment.py:83-115) for every env of the batch:

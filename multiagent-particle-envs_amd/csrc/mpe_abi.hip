@@ -22,6 +22,7 @@ struct MpeHandle {
     unsigned long long noise_seed, noise_step;
     const void* noise_draws;
     unsigned long long env_base;    // global index of the handle's first env (mpe_set_env_base), 0 by default
+    double done_bound;              // > 0: the batch's done predicate (mpe_set_done_bound); 0: no done callback
     char err[512];
 };
 
@@ -370,6 +371,7 @@ static int run(MpeHandle* h, int mode, const StepArgs& args, mpe_stream_t stream
     if (!h) return MPE_ERR_INVALID;
     StepArgs a = args;
     a.env_base = a.reset.env_base = a.au.env_base = h->env_base;
+    a.done_bound = h->done_bound;
     if (mode != 2 && h->spec.any_noise()) {
         a.noise = NoiseArgs{1, h->spec.noise_stride(), h->noise_draws, h->noise_seed, h->noise_step, h->env_base};
         if (((uintptr_t)h->noise_draws & (h->dtype == MPE_F64 ? 7u : 3u)) != 0) return fail(h, MPE_ERR_INVALID, "%s: misaligned noise draws", who);
@@ -412,6 +414,14 @@ int mpe_set_env_base(MpeHandle* h, uint64_t env_base) {
     if (!h) return MPE_ERR_INVALID;
     if (env_base > 0xffffffffffffull) return fail(h, MPE_ERR_INVALID, "mpe_set_env_base: env_base must be below 2^48");
     h->env_base = env_base;
+    return MPE_OK;
+}
+
+int mpe_set_done_bound(MpeHandle* h, double bound) {
+    if (!h) return MPE_ERR_INVALID;
+    if (h->spec.scenario == MPE_SCN_NONE) return fail(h, MPE_ERR_INVALID, "mpe_set_done_bound: a physics-only handle evaluates no callbacks");
+    if (isnan(bound)) return fail(h, MPE_ERR_INVALID, "mpe_set_done_bound: bound is NaN");
+    h->done_bound = (bound > 0.0 && isfinite(bound)) ? bound : 0.0;
     return MPE_OK;
 }
 

@@ -30,6 +30,7 @@ struct ConsensusParams {
     int wall_vertical[CW], wall_hard[CW];          // dwords: scalar loads cannot fetch single bytes of the kernel arguments
     int ghost;
     long long n_envs;
+    T done_bound;       // > 0: a world is done when an agent leaves [-done_bound, done_bound]^2 (mpe_set_done_bound)
 };
 
 // neighbors(), consensus.py:79-83: the ring neighbours of agent i in ascending order
@@ -313,6 +314,14 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
             }
         }
 
+        // ---- done_callback (environment.py:98,110-113,143-146), any(done_n) over the world's agents: an agent beyond
+        //      the bound.  The exchange area holds every agent's new position (published, barrier passed). ----
+        bool outside = false;
+        if (MODE != 2 && !pre && p.done_bound > T(0)) {
+#pragma unroll
+            for (int i = 0; i < CA; ++i)
+                outside = outside || t_abs<T>(xch[(i * 4 + 0) * XS + w]) > p.done_bound || t_abs<T>(xch[(i * 4 + 1) * XS + w]) > p.done_bound;
+        }
         // ---- reward(), consensus.py:91-113; shared by np.sum over the six agents (environment.py:103-105) ----
         const bool want_score = !pre && (MODE != 2 || rew_g != nullptr);
         if (want_score) {
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
                 // ---- episode bookkeeping (mpe_step_auto): returns, step counter, time-limit reset ----
                 T* ep = (T*)au.ep_return + b * CA;
                 const int cnt = au.step_count[b] + 1;
-                finished = cnt >= au.max_steps;
+                finished = cnt >= au.max_steps || outside;       // the time limit, or the world's own done
                 const int epi = au.episode_count[b] + 1;
                 // every thread of the world has read the counters before its first thread rewrites them
                 __syncthreads();
@@ -351,9 +360,10 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
             if (valid) {
                 rew_g[row * CA + tid] = out;        // 32 worlds x 6 rewards: six whole lines
                 // no done callback (environment.py:143-146); mpe_step_auto flags the step that reaches its time limit
-                if (MODE == 0 && a == 0) done_g[row + w] = finished ? 1 : 0;
+                if (MODE == 0 && a == 0) done_g[row + w] = (finished || outside) ? 1 : 0;
+                if (MODE == 1 && a == 0 && p.done_bound > T(0)) done_g[row + w] = outside ? 1 : 0;
             }
-            if (MODE == 1 && (env0 & 127) == 0) {
+            if (MODE == 1 && p.done_bound <= T(0) && (env0 & 127) == 0) {
                 // An episode launch has no time limit: done is 0 throughout.  A workgroup's 32 flags are a quarter of
                 // a 128-byte line: the workgroup that holds the first flag of a 128-flag block writes the whole block.
                 uint8_t* d = done_g + (long long)t * B + env0;
@@ -458,12 +468,14 @@ ConsensusParams<T> make_consensus_params(const HostSpec& s, long long B) {
     }
     p.ghost = s.ghost[0];
     p.n_envs = B;
+    p.done_bound = T(0);
     return p;
 }
 
 template <typename T>
 hipError_t launch_consensus_t(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
-    const auto p = make_consensus_params<T>(s, B);
+    auto p = make_consensus_params<T>(s, B);
+    p.done_bound = (T)a.done_bound;
     const dim3 grid((unsigned)((B + WPG - 1) / WPG)), block(NT);
     T *pos = (T*)a.pos, *vel = (T*)a.vel, *hist = (T*)a.comm, *obs = (T*)a.obs, *rew = (T*)a.rew;
     if (mode == 0 && a.noise.enabled)

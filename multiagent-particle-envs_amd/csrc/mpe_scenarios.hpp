@@ -21,6 +21,7 @@ struct SmallParams {
     T dt, one_minus_damping, contact_force, contact_margin;
     long long n_envs;
     unsigned long long env_base;                // global index of the batch's first env (counter of the respawn draws)
+    T done_bound;                               // > 0: an env is done when an agent leaves [-done_bound, done_bound]^2; 0: never
     // read by scenarios on the new_core physics with walls only
     T force_scale[A];                           // mass (* accel): new_core.py:214
     T wall_axis_pos[SMALL_MAX_WALLS], wall_end0[SMALL_MAX_WALLS], wall_end1[SMALL_MAX_WALLS], wall_width[SMALL_MAX_WALLS];

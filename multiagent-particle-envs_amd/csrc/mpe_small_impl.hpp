@@ -461,6 +461,13 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
         }
 
         STAMP_T(30);
+        // ---- done_callback (environment.py:98,110-113,143-146): any(done_n) over the agents, for the one predicate a
+        //      batch can carry -- an agent beyond the arena bound (mpe_set_done_bound); a NaN position compares false ----
+        bool outside = false;
+        if (MODE != MODE_OBSERVE && !pre && p.done_bound > T(0)) {
+#pragma unroll
+            for (int i = 0; i < A; ++i) outside = outside || t_abs<T>(pos[i].x) > p.done_bound || t_abs<T>(pos[i].y) > p.done_bound;
+        }
         // ---- scenario callbacks into the wave's LDS tiles ----
         const bool want_score = !pre && ((MODE != MODE_OBSERVE) || (rew_g != nullptr));   // observe: rewards on request
         bool finished = false;
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                 T* ep = (T*)au.ep_return + b * A;
                 const T* rrow = RewTile::row(tile_rew, tile_lane);
                 const int cnt = au.step_count[b] + 1;
-                finished = cnt >= au.max_steps;
+                finished = cnt >= au.max_steps || outside;       // the time limit, or the env's own done
                 T total[A];
 #pragma unroll
                 for (int i = 0; i < A; ++i) total[i] = ep[i] + rrow[i];
@@ -532,7 +539,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
             if constexpr (MODE == MODE_ROLLOUT && FULL && !INFO && !NOISE && Cfg::template waves_per_simd<T>() > 1) asm volatile("" : "+v"(lane_f));
             if (want_score) {
                 RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane_f, nvalid);
-                if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
+                if (MODE == MODE_ROLLOUT && FULL && EPW == 64 && p.done_bound > T(0)) {
+                    done_g[row0 + lane_f] = outside ? 1 : 0;         // a batch with a done predicate: every env its own flag
+                } else if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
                     // No scenario ends an episode (environment.py:143-146) and a rollout has no time limit, so
                     // done is 0 throughout.  A wave's 64 flags are half a 128-byte line: neighbouring waves take
                     // turns (even steps the even wave, odd steps the odd one) to write both halves as one
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                         done_g[row0 + lane_f] = 0;
                     }
                 } else if (MODE != MODE_OBSERVE && valid) {
-                    done_g[row0 + lane_f] = finished ? 1 : 0;
+                    done_g[row0 + lane_f] = (finished || outside) ? 1 : 0;
                 }
                 if (want_info) {
                     IiTile::template flush<FULL>(tile_ii, info_i_g + row0 * NI, lane_f, nvalid);
@@ -731,6 +740,7 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     p.contact_margin = (T)s.contact_margin;
     p.n_envs = n_envs;
     p.env_base = env_base;
+    p.done_bound = T(0);
     for (int e = 0; e < Cfg::E; ++e) p.size_d[e] = s.size[e];
     for (int i = 0; i < Cfg::A; ++i) { p.u_noise[i] = (T)s.u_noise[i]; p.c_noise[i] = (T)s.c_noise[i]; }
     for (int i = 0; i < Cfg::A; ++i) { p.force_scale[i] = (T)s.force_scale[i]; p.ghost[i] = s.ghost[i]; }
@@ -782,7 +792,8 @@ static void launch_mode(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, co
 
 template <typename T, class Cfg, bool CLAMP>
 static hipError_t launch_cfg(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
-    const auto p = make_params<T, Cfg>(s, B, a.env_base);
+    auto p = make_params<T, Cfg>(s, B, a.env_base);
+    p.done_bound = (T)a.done_bound;
     const bool info = a.info_i != nullptr;
     switch (mode) {
         case MODE_STEP:

@@ -33,6 +33,7 @@ struct WaveParams {
     T dt, one_minus_damping, contact_force, contact_margin;
     long long n_envs;
     int A, L, dim_c, n_speak_rows;
+    T done_bound;       // > 0: a world is done when an agent leaves [-done_bound, done_bound]^2 (mpe_set_done_bound)
 };
 
 template <typename T> __device__ __forceinline__ T spread_round(T v) { return (T)(float)v; }
@@ -276,6 +277,10 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
 
         if (EPI == EPI_SPREAD) {
             bool finished = false;
+            // done_callback (environment.py:98,110-113,143-146), any(done_n) over the agents: an agent beyond the bound
+            bool outside = false;
+            if (MODE != WMODE_OBSERVE && p.done_bound > T(0))
+                outside = __syncthreads_or(is_agent && (t_abs<T>(P[me].x) > p.done_bound || t_abs<T>(P[me].y) > p.done_bound)) != 0;
             // The observation needs the new positions, not the rewards: in a launch of one step every other world
             // emits it before its rewards, so that one world's rows leave while its neighbour on the CU runs the reward
             // loops (worlds launched together are in step, and one step gives them no time to drift apart: 38.3 ->
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                     if (MODE == WMODE_STEP && au.step_count != nullptr) {
                         T* ep = (T*)au.ep_return + b * A;
                         const T total = ep[lane] + r_me;
-                        const bool fin = au.step_count[b] + 1 >= au.max_steps;
+                        const bool fin = au.step_count[b] + 1 >= au.max_steps || outside;
                         ep[lane] = fin ? T(0) : total;
                         if (fin) ((T*)au.last_return)[b * A + lane] = total;
                     }
@@ -340,7 +345,9 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
                 // No scenario ends an episode (environment.py:143-146): done is 0 unless mpe_step_auto's time limit
                 // sets it (below).  A world's flag is one byte of a 128-byte line, so the world that holds the first
                 // flag of a 128-flag block writes the whole block.
-                if (MODE != WMODE_OBSERVE && au.step_count == nullptr && (b & 127) == 0) {
+                if (MODE != WMODE_OBSERVE && au.step_count == nullptr && p.done_bound > T(0)) {
+                    if (lane == 0) done_g[row] = outside ? 1 : 0;       // a batch with a done predicate: every world its own flag
+                } else if (MODE != WMODE_OBSERVE && au.step_count == nullptr && (b & 127) == 0) {
                     uint8_t* d = done_g + row;
                     const long long n = B - b < 128 ? B - b : 128;
                     if ((((unsigned long long)(uintptr_t)d) & 3u) == 0 && n == 128) {
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
             if (MODE == WMODE_STEP && au.step_count != nullptr) {
                 // ---- episode bookkeeping (mpe_step_auto): step counter and time-limit reset ----
                 const int cnt = au.step_count[b] + 1;       // read by every thread before thread 0 updates it
-                finished = cnt >= au.max_steps;
+                finished = cnt >= au.max_steps || outside;       // the time limit, or the world's own done
                 const int epi = au.episode_count[b] + (finished ? 1 : 0);
                 __syncthreads();
                 if (lane == 0) {
@@ -392,6 +399,7 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
     p.contact_margin = (T)s.contact_margin;
     p.n_envs = B;
     p.A = s.A; p.L = s.L; p.dim_c = s.dim_c; p.n_speak_rows = n_speak_rows;
+    p.done_bound = (T)a.done_bound;
     const dim3 grid((unsigned)B), block(NT);
     if constexpr (EPI == EPI_SPREAD && MODE == WMODE_STEP) {
         if (a.noise.enabled) {

@@ -37,7 +37,7 @@ class BatchedEnv:
     """
 
     def __init__(self, scenario, n_envs, dtype=torch.float32, device="cuda:0", info=False, max_episode_steps=None, seed=0,
-                 scripted=None, env_base=0, **spec_kw):
+                 scripted=None, env_base=0, done_bound=None, **spec_kw):
         self.spec = scenario if isinstance(scenario, WorldSpec) else make_spec(scenario, **spec_kw)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -60,6 +60,11 @@ class BatchedEnv:
         self.env_base = int(env_base)
         if self.env_base:
             _lib.check(h, self._lib.mpe_set_env_base(h, self.env_base))
+        # done_callback of the batch (multiagent/environment.py:143-146 combined by any(done_n), :110-113): an env is
+        # done when an agent is outside [-done_bound, done_bound]^2.  None = the reference's default, no done callback.
+        self.done_bound = None if done_bound is None else float(done_bound)
+        if self.done_bound is not None:
+            _lib.check(h, self._lib.mpe_set_done_bound(h, self.done_bound))
         lo = _lib.MpeLayout()
         _lib.check(h, self._lib.mpe_layout(h, C.byref(lo)))
         self.layout = lo
@@ -332,7 +337,7 @@ class BatchedEnv:
             v = getattr(self.spec, f.name)
             h.update(f.name.encode() + b"=")
             h.update(np.asarray(v, dtype=np.float64).tobytes() if isinstance(v, np.ndarray) else repr(v).encode())
-        h.update(repr((self.max_episode_steps, self.env_major, self.env_base)).encode())
+        h.update(repr((self.max_episode_steps, self.env_major, self.env_base, self.done_bound)).encode())
         return h.hexdigest()[:32]
 
     def _noise_state(self, put=None):

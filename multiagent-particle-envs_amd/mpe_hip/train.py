@@ -58,12 +58,12 @@ class BatchedVecEnv:
     between calls."""
 
     def __init__(self, scenario, num_envs, max_episode_steps=25, seed=0, dtype=torch.float32, device="cuda:0", info=False, env_base=0,
-                 **spec_kw):
+                 done_bound=None, **spec_kw):
         # env_base: global index of this process's first env (rank r of a G-process job with num_envs envs each passes
         # r * num_envs and the job's one seed, as the reference's vec-env factory derives each env's seed from its
         # global position, multiagent/backup/mappo.py:97,113)
         self.env = BatchedEnv(scenario, num_envs, dtype=dtype, device=device, info=info, max_episode_steps=max_episode_steps, seed=seed,
-                              env_base=env_base, **spec_kw)
+                              env_base=env_base, done_bound=done_bound, **spec_kw)
         self.num_envs = int(num_envs)
         self.n_agents = self.env.n_agents
         self.seed = int(seed)

@@ -981,6 +981,13 @@ def pp_env_step(spec: Spec, pos, vel, actions, alive, holding, respawn_pos):
     return pos, vel, obs, rew, alive, holding
 
 
+def done_outside(spec: Spec, pos, bound) -> np.ndarray:
+    """MultiAgentEnv.step's done for the done_callback `lambda agent, world: any(|agent.state.p_pos| > bound)`:
+    _get_done per agent (environment.py:98,143-146), then any(done_n) (:110-113).  pos [B, E, 2] after World.step."""
+    done_n = [np.any(np.abs(pos[:, i, :]) > bound, axis=1) for i in range(spec.A)]
+    return np.any(np.stack(done_n, axis=1), axis=1)
+
+
 # --------------------------------------------------------------------------
 # The counter-based generator of the on-device reset and respawn: Philox-4x32-10 (Salmon et al.,
 # "Parallel random numbers: as easy as 1, 2, 3", SC'11), restated in numpy so that the device's

@@ -357,3 +357,18 @@ def test_decided_with_margin_marks_envs_whose_integers_survive_perturbation(case
                 for a, b in zip(orc.visibility_masks(spec, moved), orc.visibility_masks(spec, pos)):
                     assert np.array_equal(a[sure], b[sure]), (case, t)
     assert rejected > 0
+
+
+def test_done_callback_restatement_matches_the_reference():
+    """done.npz: the reference's MultiAgentEnv.step on simple_tag with done_callback = "the agent is beyond the bound";
+    the oracle's done_outside on the oracle's own free-running trajectory gives the same flags at every step."""
+    g = load_golden("done")
+    spec = orc.make_spec("simple_tag")
+    pos, vel = g["pos0"].copy(), g["vel0"].copy()
+    bound = float(g["bound"])
+    for t in range(g["actions"].shape[0]):
+        pos, vel, *_ = orc.env_step(spec, pos, vel, g["actions"][t])
+        assert np.array_equal(pos[:, :spec.A], g["pos"][t])
+        assert np.array_equal(orc.done_outside(spec, pos, bound), g["done"][t].astype(bool)), t
+        assert np.array_equal(np.any(np.abs(pos[:, :spec.A]) > bound, axis=2), g["done_n"][t].astype(bool)), t
+    assert g["done"].any() and not g["done"].all()

@@ -969,6 +969,34 @@ def run_noise(ref, seed=20240681, B=8, T=10):
     return rec
 
 
+def run_done(ref, seed=20240602, bound=1.0):
+    """simple_tag through MultiAgentEnv.step with a done_callback (environment.py:15-18): the agent is beyond the
+    arena bound in either coordinate -- what the comment at environment.py:141-142 has in mind.  step returns
+    any(done_n) (:98,110-113).  Same initial states and actions as tag.npz (its envs 9..15 head outwards)."""
+    rng = np.random.RandomState(seed)
+    pos0, vel0, actions = init_tag(rng)
+    sc = ref.scenarios["simple_tag"].Scenario()
+    world = sc.make_world()
+    done_cb = lambda agent, w: bool(np.any(np.abs(agent.state.p_pos) > bound))
+    env = ref.environment.MultiAgentEnv(world, lambda w, rng_: sc.reset_world(w), sc.reward, sc.observation, sc.benchmark_data,
+                                        done_callback=done_cb)
+    T, B, A = actions.shape
+    rec = {"pos0": pos0, "vel0": vel0, "actions": actions.astype(np.int32), "bound": np.float64(bound),
+           "pos": np.zeros((T, B, A, 2)), "done": np.zeros((T, B), np.uint8), "done_n": np.zeros((T, B, A), np.uint8)}
+    env.seed(0)
+    for b in range(B):
+        env.reset()
+        inject(world, pos0[b], vel0[b])
+        for t in range(T):
+            _, _, done, _ = env.step([int(a) for a in actions[t, b]])
+            assert done is True or done is False            # a single bool (environment.py:110-113)
+            rec["done"][t, b] = done
+            rec["done_n"][t, b] = [env._get_done(ag) for ag in world.agents]
+            rec["pos"][t, b] = [ag.state.p_pos for ag in world.agents]
+    print("done: done steps", int(rec["done"].sum()), "of", T * B, "; envs ever done", int(rec["done"].any(axis=0).sum()))
+    return rec
+
+
 def run_gae(ref, seed=20240671):
     """Advantages and returns from the reference's own Runner.run (multiagent/backup/runner_old.py:39-80,
     the nenv > 1 branch): the runner is driven with a scripted env and model that replay fixed rewards,
@@ -1061,9 +1089,14 @@ def known_answers(ref):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--only", default=None, help="write this fixture alone (supported: done)")
     args = ap.parse_args()
     ref = load_reference()
     os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "done.npz"), **run_done(ref))
+    print("wrote done.npz")
+    if args.only == "done":
+        return
     cases = {}
 
     rng = np.random.RandomState(20240601)
