@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
 #pragma unroll
                     for (int i = 0; i < CA * 4 * WPG / NT; ++i) {
                         const int j = i * NT + tid, r = j / WPG, wj = j - r * WPG;
-                        if (wj < nvalid) hist_g[(long long)(head * CA * 4 + r) * B + env0 + wj] = xch[r * XS + wj];
+                        if (wj < nvalid) put<MODE == 0>(&hist_g[(long long)(head * CA * 4 + r) * B + env0 + wj], xch[r * XS + wj]);
                     }
                 } else if (valid) {
                     hist_g[hrow(head, 0)] = pos.x; hist_g[hrow(head, 1)] = pos.y;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
                 reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0, au.env_base}, finished, 0);
             }
             if (valid) {
-                rew_g[row * CA + tid] = out;        // 32 worlds x 6 rewards: six whole lines
+                put<MODE == 0>(&rew_g[row * CA + tid], out);        // 32 worlds x 6 rewards: six whole lines
                 // no done callback (environment.py:143-146); mpe_step_auto flags the step that reaches its time limit
                 if (MODE == 0 && a == 0) done_g[row + w] = (finished || outside) ? 1 : 0;
                 if (MODE == 1 && a == 0 && p.done_bound > T(0)) done_g[row + w] = outside ? 1 : 0;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
 #pragma unroll 5
                 for (int i = 0; i < NVT / 64; ++i) {
                     const int g = i * 64 + lane, ar = g / NVA, j = g - ar * NVA;
-                    if (row0 + ar < rows_valid) dst[g] = *reinterpret_cast<const VT*>(my_tile + ar * PAD + j * VEC);
+                    if (row0 + ar < rows_valid) put<MODE == 0>(&dst[g], *reinterpret_cast<const VT*>(my_tile + ar * PAD + j * VEC));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
             for (int i = 0; i < CA * 4 * WPG / NT; ++i) {
                 const int j = i * NT + tid, r = j / WPG, wj = j - r * WPG, c = r & 3;
                 T* const dst = (c < 2) ? pos_g : vel_g;
-                if (wj < nvalid) dst[(long long)(2 * (r >> 2) + (c & 1)) * B + env0 + wj] = xch[r * XS + wj];
+                if (wj < nvalid) put<MODE == 0>(&dst[(long long)(2 * (r >> 2) + (c & 1)) * B + env0 + wj], xch[r * XS + wj]);
             }
             // every world's own head: a time-limit reset inside the launch (mpe_step_auto) puts the worlds it resets
             // back to slot 0 while their neighbours advance, so the heads may differ by now

@@ -11,6 +11,8 @@
 // A workgroup is a single 64-lane wave: the LDS tiles are private to the wave, so the
 // __syncthreads() below are plain LDS waits, not hardware barriers.
 #pragma once
+#include <type_traits>
+
 #include "mpe_scenarios.hpp"
 #include "mpe_launch.hpp"
 
@@ -39,7 +41,8 @@ struct Tile {
 
     // FULL: all 64 envs valid and gdst 16-byte aligned (fixed per kernel instantiation, so the
     // fast path is straight-line code and the compiler can count outstanding stores)
-    template <bool FULL>
+    // NT: non-temporal stores (see put<> below): the launches of a single step use them
+    template <bool FULL, bool NT = false>
     __device__ static __forceinline__ void flush(const V* tile, V* gdst, int lane, int nvalid) {
         if (LINEAR && FULL) {
             typedef V VT __attribute__((ext_vector_type(VEC)));
@@ -48,8 +51,8 @@ struct Tile {
             const VT* src = reinterpret_cast<const VT*>(tile);
             VT* dst = reinterpret_cast<VT*>(gdst);
 #pragma unroll
-            for (int it = 0; it < FULL_IT; ++it) dst[it * 64 + lane] = src[it * 64 + lane];
-            if (REM > 0 && lane < REM) dst[FULL_IT * 64 + lane] = src[FULL_IT * 64 + lane];
+            for (int it = 0; it < FULL_IT; ++it) put<NT>(&dst[it * 64 + lane], src[it * 64 + lane]);
+            if (REM > 0 && lane < REM) put<NT>(&dst[FULL_IT * 64 + lane], src[FULL_IT * 64 + lane]);
         } else if (!LINEAR && FULL && W % VEC == 0) {
             // padded rows, 16-byte stores: vector g covers values [VEC * (g % NVR), + VEC) of row g / NVR
             typedef V VT __attribute__((ext_vector_type(VEC)));
@@ -61,7 +64,7 @@ struct Tile {
                 VT v;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) v[q] = tile[r * STRIDE + j + q];
-                if (NV % 64 == 0 || g < NV) *reinterpret_cast<VT*>(gdst + r * W + j) = v;
+                if (NV % 64 == 0 || g < NV) put<NT>(reinterpret_cast<VT*>(gdst + r * W + j), v);
             }
         } else {
             const int n = nvalid * W;
@@ -69,10 +72,10 @@ struct Tile {
             for (int it = 0; it < (ROWS * W + 63) / 64; ++it) {
                 const int g = it * 64 + lane;
                 if (LINEAR) {
-                    if (g < n) gdst[g] = tile[g];
+                    if (g < n) put<NT>(&gdst[g], tile[g]);
                 } else {
                     const int r = g / W;
-                    if (g < n) gdst[g] = tile[r * STRIDE + (g - r * W)];
+                    if (g < n) put<NT>(&gdst[g], tile[r * STRIDE + (g - r * W)]);
                 }
             }
         }
@@ -90,7 +93,7 @@ struct ChunkTile {
     static constexpr int STRIDE = LINEAR ? Cfg::CHUNK_MAX : (Cfg::CHUNK_MAX | 1);
 };
 
-template <typename T, class Cfg, int C, int EPW, bool FULL>
+template <typename T, class Cfg, int C, int EPW, bool FULL, bool NT = false>
 struct ObsChunks {
     static constexpr int W = Cfg::chunk_width(C), S = ChunkTile<T, Cfg>::STRIDE, COL0 = Cfg::chunk_offset(C);
     static constexpr int VEC = 16 / (int)sizeof(T);
@@ -111,7 +114,7 @@ struct ObsChunks {
                 VT v;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) v[q] = tile[r * S + j + q];
-                if (NV % 64 == 0 || g < NV) *reinterpret_cast<VT*>(gbase + (long long)r * Cfg::OBS_TOTAL + COL0 + j) = v;
+                if (NV % 64 == 0 || g < NV) put<NT>(reinterpret_cast<VT*>(gbase + (long long)r * Cfg::OBS_TOTAL + COL0 + j), v);
             }
         } else {
             const int n = nvalid * W;
@@ -119,19 +122,20 @@ struct ObsChunks {
             for (int it = 0; it < (EPW * W + 63) / 64; ++it) {
                 const int g = it * 64 + lane;
                 const int r = g / W;
-                if (g < n) gbase[(long long)r * Cfg::OBS_TOTAL + COL0 + (g - r * W)] = tile[r * S + (g - r * W)];
+                if (g < n) put<NT>(&gbase[(long long)r * Cfg::OBS_TOTAL + COL0 + (g - r * W)], tile[r * S + (g - r * W)]);
             }
         }
         __syncthreads();
         if constexpr (C + 1 < Cfg::OBS_CHUNKS)
-            ObsChunks<T, Cfg, C + 1, EPW, FULL>::run(pos, vel, comm, aux, ctx, tile, gbase, lane, tile_lane, active, nvalid);
+            ObsChunks<T, Cfg, C + 1, EPW, FULL, NT>::run(pos, vel, comm, aux, ctx, tile, gbase, lane, tile_lane, active, nvalid);
     }
 };
 
 #ifdef MPE_STAMPS
 // Diagnostic build only: 100 MHz timestamps per workgroup (slot 0 start, 1 state and actions ready,
-// 2+t step t computed and its rows issued, 60 all steps done; within step 10: 30 physics done, 31 rewards
-// done, 32 state staged, 33.. cooperative pass k flushed, 41 post_step done).  tools/probes/episode_stamps.py
+// 2+t step t computed and its rows issued, 60 all steps done, 61 the final state's stores issued, 62 every store of
+// the wave acknowledged; within step 10: 30 physics done, 31 rewards done, 32 state staged, 33.. cooperative pass k
+// flushed, 41 post_step done).  tools/probes/episode_stamps.py
 // and tools/probes/step_phases.py read them.
 __device__ long long g_stamps[4096 * 64];
 }  // namespace mpe
@@ -154,7 +158,14 @@ namespace mpe {
 //   reset_kernel would (Scenario.reset_world), so an episode is a single launch.
 // NOISE: the world has agents with u_noise / c_noise (its own instantiation: the generator is an out-of-line
 //   call, and a kernel with a call site pays for the calling convention in registers on every path).
-template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false>
+// PACKED (rollout launches, no benchmark outputs): ONE output stream.  obs_g is then T[n_steps][B][OT + A + 1], the row
+//   of a world-step being its observation, its A rewards and its done flag (0.0 / 1.0) back to back; rew_g and done_g
+//   are not written.  A wave's 64 rows are one contiguous block of whole 128-byte lines (256 * row values bytes).  At
+//   65 536 worlds, one wave per SIMD, every further store stream of a wave costs more than its bytes -- without the
+//   reward rows (6 % of the bytes) the episode launch is 11 % shorter, and rocprofv3 counters put the difference in
+//   the waves' own waiting at the store issue (SQ_WAIT_ANY -26 %, the vector L1's pending stalls -12 %), not in the
+//   fabric (DRAM credit stalls -5 %) -- while the same bytes inside the observation rows' stream cost their share.
+template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false, bool PACKED = false>
 __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOISE) ? Cfg::template waves_per_simd<T>() : 1) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs, const AutoArgs au,
                                                    const long long env_begin, const long long env_end,
                                                    const int* __restrict__ actions, T* __restrict__ pos_g,
@@ -164,6 +175,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                                                    T* __restrict__ info_f_g, int* __restrict__ aux_g, T* __restrict__ obs0_g, const NoiseArgs nz,
                                                    int n_steps) {
     constexpr int A = Cfg::A, E = Cfg::E, OT = Cfg::OBS_TOTAL, NA = Cfg::N_ACT;
+    constexpr bool NT = MODE == MODE_STEP && Cfg::NT_STEP;      // a single step's outputs leave as non-temporal stores (see put<>)
     constexpr int NI = Cfg::NI > 0 ? Cfg::NI : 1, NF = Cfg::NF > 0 ? Cfg::NF : 1, DC = Cfg::DIM_C, NX = Cfg::N_AUX;
     constexpr int NC = Cfg::S * Cfg::DIM_C;      // comm state values: the speakers' utterances in agent order
     constexpr int OW = Cfg::OBS_CHUNKS > 1 ? Cfg::CHUNK_MAX : OT;        // columns held by the observation tile
@@ -173,7 +185,12 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
     constexpr bool COOP = Cfg::OBS_COOP;                                 // whole rows of 8 worlds per pass, lanes = worlds x agents
     static_assert(!COOP || (EPW == 64 && A <= 8 && !Cfg::OBS_LOOP && RP == 0), "cooperative passes regroup a full wave as 8 worlds x up to 8 agents");
     constexpr int TROWS = COOP ? 8 : (RP > 0 ? EPW / RP : EPW);
-    using ObsTile = Tile<T, (COOP ? OT : OW), (COOP ? true : LIN), TROWS>;
+    static_assert(!PACKED || (MODE == MODE_ROLLOUT && !INFO && Cfg::OBS_CHUNKS == 1 && !COOP && RP == 0 && !Cfg::OBS_LOOP),
+                  "packed rows: rollout launches of the scenarios whose row leaves in one flush");
+    constexpr int PW = OT + A + 1;                                       // packed row: observation, rewards, done
+    constexpr bool LINP = ((PW * (int)sizeof(T) / 4) % 16) != 0;
+    using ObsTile0 = Tile<T, (COOP ? OT : OW), (COOP ? true : LIN), TROWS>;      // rows of observations only
+    using ObsTile = std::conditional_t<PACKED, Tile<T, PW, LINP, TROWS>, ObsTile0>;
     using CoopStage = StagedRows<T, E, A, Cfg::template stage_packed<T>()>;
     using RewTile = Tile<T, A, true, EPW>;
     using IiTile = Tile<int, NI, true, EPW>;
@@ -472,13 +489,15 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
         const bool want_score = !pre && ((MODE != MODE_OBSERVE) || (rew_g != nullptr));   // observe: rewards on request
         bool finished = false;
         if (EPW == 64 || lane < EPW) {
+            // the agents' rewards: a row of the reward tile, or (packed rows) the columns behind the observation
+            T* const rrow = PACKED ? ObsTile::row(tile_obs, tile_lane) + OT : RewTile::row(tile_rew, tile_lane);
             if (want_score)
-                Cfg::template score<T>(pos, comm, aux, p, RewTile::row(tile_rew, tile_lane), want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
+                Cfg::template score<T>(pos, comm, aux, p, rrow, want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
+            if (PACKED && want_score) rrow[A] = outside ? T(1) : T(0);      // done: no callback (environment.py:143-146) or the bound
             if (Cfg::SHARED && MODE != MODE_OBSERVE && !pre) {
                 // collaborative world: step hands every agent np.sum(reward_n) (environment.py:103-105);
                 // numpy adds fewer than 8 values left to right
                 static_assert(!Cfg::SHARED || A < 8, "np.sum switches to pairwise blocks at 8 values");
-                T* rrow = RewTile::row(tile_rew, tile_lane);
                 T total = rrow[0];
 #pragma unroll
                 for (int i = 1; i < A; ++i) total = total + rrow[i];
@@ -488,7 +507,6 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
             if (MODE == MODE_STEP && au.step_count != nullptr) {
                 // ---- episode bookkeeping (mpe_step_auto): returns, step counter, time-limit reset ----
                 T* ep = (T*)au.ep_return + b * A;
-                const T* rrow = RewTile::row(tile_rew, tile_lane);
                 const int cnt = au.step_count[b] + 1;
                 finished = cnt >= au.max_steps || outside;       // the time limit, or the env's own done
                 T total[A];
@@ -527,18 +545,24 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                     }
                 }
             }
-            if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
+            if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP)
+                Cfg::template observe<T>(pos, vel, comm, aux, p, (PACKED && pre) ? ObsTile0::row(tile_obs, tile_lane) : ObsTile::row(tile_obs, tile_lane));
         }
         STAMP_T(31);
         const long long row0 = (long long)t * B + env0;
-        T* const obs_dst = pre ? obs0_g + (ep_idx * B + env0) * OT : obs_g + row0 * OT;
+        T* const obs_dst = pre ? obs0_g + (ep_idx * B + env0) * OT : obs_g + row0 * (PACKED ? PW : OT);
         auto flush_small = [&]() {
             // (a kernel on a tight register budget: an opaque copy of the lane keeps the flushes' addresses per-step
             // work; hoisted out of the step loop they are spilled, and every reload waits for the wave's older stores)
             int lane_f = lane;
             if constexpr (MODE == MODE_ROLLOUT && FULL && !INFO && !NOISE && Cfg::template waves_per_simd<T>() > 1) asm volatile("" : "+v"(lane_f));
-            if (want_score) {
-                RewTile::template flush<FULL>(tile_rew, rew_g + row0 * A, lane_f, nvalid);
+            if (want_score && !PACKED) {
+#ifdef MPE_ABLATE_REW
+                // Diagnostic build only (tools/pmc_headline.py): the reward rows stay computed but are not stored, behind
+                // a condition the compiler cannot fold, to price that output stream with counters.
+                if (n_steps == 0x7fffffff)
+#endif
+                RewTile::template flush<FULL, NT>(tile_rew, rew_g + row0 * A, lane_f, nvalid);
                 if (MODE == MODE_ROLLOUT && FULL && EPW == 64 && p.done_bound > T(0)) {
                     done_g[row0 + lane_f] = outside ? 1 : 0;         // a batch with a done predicate: every env its own flag
                 } else if (MODE == MODE_ROLLOUT && FULL && EPW == 64) {
@@ -555,11 +579,11 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                         done_g[row0 + lane_f] = 0;
                     }
                 } else if (MODE != MODE_OBSERVE && valid) {
-                    done_g[row0 + lane_f] = (finished || outside) ? 1 : 0;
+                    put<NT>(&done_g[row0 + lane_f], (uint8_t)((finished || outside) ? 1 : 0));
                 }
                 if (want_info) {
-                    IiTile::template flush<FULL>(tile_ii, info_i_g + row0 * NI, lane_f, nvalid);
-                    if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::template flush<FULL>(tile_if, info_f_g + row0 * NF, lane_f, nvalid);
+                    IiTile::template flush<FULL, NT>(tile_ii, info_i_g + row0 * NI, lane_f, nvalid);
+                    if (Cfg::NF > 0 && info_f_g != nullptr) IfTile::template flush<FULL, NT>(tile_if, info_f_g + row0 * NF, lane_f, nvalid);
                 }
             }
         };
@@ -593,7 +617,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                 if (j >= W2) { j -= W2; ++r; }
 #pragma unroll 4
                 for (int g = lane; g < n; g += 64) {
-                    gbase[r * (OT / 2) + j] = tile2[r * (S / 2) + j];
+                    put<NT>(&gbase[r * (OT / 2) + j], tile2[r * (S / 2) + j]);
                     j += 64 - W2;
                     ++r;
                     if (j >= W2) { j -= W2; ++r; }
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                 __syncthreads();
                 int nv = nvalid - pass * TROWS;
                 nv = nv < 0 ? 0 : (nv > TROWS ? TROWS : nv);
-                ObsTile::template flush<FULL>(tile_obs, obs_dst + (long long)(pass * TROWS) * OT, lane, nv);
+                ObsTile::template flush<FULL, NT>(tile_obs, obs_dst + (long long)(pass * TROWS) * OT, lane, nv);
                 __syncthreads();
                 STAMP_T(33 + pass);
             }
@@ -642,7 +666,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                 __syncthreads();
                 int nv = nvalid - pass * TROWS;
                 nv = nv < 0 ? 0 : (nv > TROWS ? TROWS : nv);
-                ObsTile::template flush<FULL>(tile_obs, obs_dst + (long long)(pass * TROWS) * OT, lane, nv);
+                ObsTile::template flush<FULL, NT>(tile_obs, obs_dst + (long long)(pass * TROWS) * OT, lane, nv);
                 __syncthreads();
             }
         } else if constexpr (Cfg::OBS_CHUNKS > 1)
@@ -652,7 +676,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
             // per-step work and frees those registers.
             int lane_s = lane;
             asm volatile("" : "+v"(lane_s));
-            ObsChunks<T, Cfg, 0, EPW, FULL>::run(pos, vel, comm, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_dst, lane_s,
+            ObsChunks<T, Cfg, 0, EPW, FULL, NT>::run(pos, vel, comm, aux, Cfg::template observe_prepare<T>(pos, p), tile_obs, obs_dst, lane_s,
                                                  tile_lane, EPW == 64 || lane < EPW, nvalid);
         }
         // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
@@ -660,7 +684,10 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
         if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, p.env_base + (unsigned long long)b);
         __syncthreads();
         STAMP_T(41);
-        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) ObsTile::template flush<FULL>(tile_obs, obs_dst, lane, nvalid);
+        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) {
+            if (PACKED && pre) ObsTile0::template flush<FULL, NT>(tile_obs, obs_dst, lane, nvalid);      // the reset observation: rows of OT values
+            else ObsTile::template flush<FULL, NT>(tile_obs, obs_dst, lane, nvalid);
+        }
         if constexpr (!COOP) flush_small();
         if (MODE == MODE_ROLLOUT) {
             if (t >= 0 && t < 28) STAMP(2 + t);
@@ -675,25 +702,30 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
     if (MODE != MODE_OBSERVE && valid) {
 #pragma unroll
         for (int i = 0; i < A; ++i) {
-            pos_g[(long long)(2 * i) * B + b] = pos[i].x;
-            pos_g[(long long)(2 * i + 1) * B + b] = pos[i].y;
-            vel_g[(long long)(2 * i) * B + b] = vel[i].x;
-            vel_g[(long long)(2 * i + 1) * B + b] = vel[i].y;
+            put<NT>(&pos_g[(long long)(2 * i) * B + b], pos[i].x);
+            put<NT>(&pos_g[(long long)(2 * i + 1) * B + b], pos[i].y);
+            put<NT>(&vel_g[(long long)(2 * i) * B + b], vel[i].x);
+            put<NT>(&vel_g[(long long)(2 * i + 1) * B + b], vel[i].y);
         }
         if (NC > 0) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) comm_g[(long long)c * B + b] = comm[c];
+            for (int c = 0; c < NC; ++c) put<NT>(&comm_g[(long long)c * B + b], comm[c]);
         }
         if (Cfg::DYNAMIC) {     // post_step moves landmarks and rewrites the scenario's int state
 #pragma unroll
             for (int e = A; e < E; ++e) {
-                pos_g[(long long)(2 * e) * B + b] = pos[e].x;
-                pos_g[(long long)(2 * e + 1) * B + b] = pos[e].y;
+                put<NT>(&pos_g[(long long)(2 * e) * B + b], pos[e].x);
+                put<NT>(&pos_g[(long long)(2 * e + 1) * B + b], pos[e].y);
             }
 #pragma unroll
-            for (int k = 0; k < NX; ++k) aux_g[(long long)k * B + b] = aux[k];
+            for (int k = 0; k < NX; ++k) put<NT>(&aux_g[(long long)k * B + b], aux[k]);
         }
     }
+#ifdef MPE_STAMPS
+    STAMP(61);                                      // every store of the wave issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(62);                                      // ... and acknowledged
+#endif
 }
 
 // Scenario.post_step alone, for a caller that runs it as MultiAgentEnv's post_step_callback between its
@@ -753,11 +785,11 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     return p;
 }
 
-template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false>
+template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false, bool PACKED = false>
 static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_begin, long long env_end, const StepArgs& a, hipStream_t st) {
     if (env_end <= env_begin) return;
     const dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
-    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW, NOISE>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
+    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW, NOISE, PACKED>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
                        (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.aux, (T*)a.obs0, a.noise, a.n_steps);
 }
 
@@ -772,6 +804,13 @@ static void launch_epw(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, con
         }
     }
     const long long n_full = ((B & 3) == 0) ? (B / EPW) * EPW : 0;
+    if constexpr (MODE == MODE_ROLLOUT && !INFO && Cfg::PACKABLE) {
+        if (a.packed) {     // one output stream (mpe_rollout_rows / mpe_episode_rows)
+            launch_range<T, Cfg, CLAMP, MODE, true, INFO, EPW, false, true>(p, 0, n_full, a, st);
+            launch_range<T, Cfg, CLAMP, MODE, false, INFO, (EPW < 64 ? EPW : 64), false, true>(p, n_full, B, a, st);
+            return;
+        }
+    }
     launch_range<T, Cfg, CLAMP, MODE, true, INFO, EPW>(p, 0, n_full, a, st);
     launch_range<T, Cfg, CLAMP, MODE, false, INFO, (EPW < 64 ? EPW : 64)>(p, n_full, B, a, st);
 }

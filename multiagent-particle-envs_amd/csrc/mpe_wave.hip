@@ -142,6 +142,8 @@ __global__ __launch_bounds__(NT) void wave_kernel(const WaveParams<T> p, const R
     // Pair r of agent i's row is Vel[i] (r = 0), P[i] (r = 1) or P[src] - P[i]; the loop is branch-
     // free (one computed index into PV, the subtrahend masked out for r < 2) so that the LDS
     // reads of several iterations are in flight together, and (i, r) advance incrementally.
+    // (Plain stores also in a launch of one step: as non-temporal 8-byte stores, see put<>, the block took 37.4 us
+    // instead of 35.4 at 64/64 x 2 048 worlds.)
     auto emit_obs = [&](T* world_block) {
         const int RP = OD / 2, total = A * RP;
         typedef T T2 __attribute__((ext_vector_type(2)));

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for rep in 1 2; do
 for v in "$@"; do
   if [ "$v" = base ]; then lib=""; else lib="$PWD/variants/libmpe_$v.so"; fi
-  MPE_HIP_LIB=$lib timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-step-mode $args > gpurun_out/ab_${v}_$rep.json || exit 1
+  MPE_HIP_LIB=$lib timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-step-mode --no-configs --no-sustained $args > gpurun_out/ab_${v}_$rep.json || exit 1
   python3 - "$v" "$rep" <<'PY'
 import json,sys
 v,rep=sys.argv[1:3]

@@ -60,7 +60,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     os.environ.update(env)
-    bench = ["python3", "bench.py", "--no-cpu-baseline", "--scenario", args.scenario, "--envs", str(args.envs),
+    bench = ["python3", "bench.py", "--no-cpu-baseline", "--no-configs", "--no-sustained", "--scenario", args.scenario, "--envs", str(args.envs),
              "--dtype", args.dtype, "--mode", args.mode] + [a for a in extra if a != "--"]
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(out, "stats"), "--"] + bench,
              os.path.join(out, "stats.log"), 400)

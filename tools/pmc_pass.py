@@ -20,12 +20,12 @@ if "--" in names:       # bench.py arguments after a "--", e.g. -- --agents 64 -
     names = names[:names.index("--")]
 out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%d" % (scn, os.getpid()))
 os.environ["TMPDIR"] = "/tmp"
-cmd = ["rocprofv3", "--pmc"] + names + ["--output-format", "csv", "-d", out, "--", "python3", "bench.py", "--no-cpu-baseline", "--no-step-mode",
+cmd = ["rocprofv3", "--pmc"] + names + ["--output-format", "csv", "-d", out, "--", "python3", "bench.py", "--no-cpu-baseline", "--no-step-mode", "--no-configs", "--no-sustained",
                                         "--scenario", scn, "--envs", envs, "--steps", "250", "--warmup", "25", "--target-steps", "250"] + extra
 rc = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200).returncode
 if rc != 0:
     sys.exit("rocprofv3 failed with %d" % rc)
-mode_re = re.compile(r"(?:>|Cfg), (?:true|false), 1, (?:true|false), (?:true|false), \d+>\(|consensus_kernel<\w+, 1>|wave_kernel<\w+, 1, 0")
+mode_re = re.compile(r"(?:>|Cfg), (?:true|false), 1, (?:true|false), (?:true|false), \d+(?:, (?:true|false))?>\(|consensus_kernel<\w+, 1(?:, (?:true|false))?>|wave_kernel<\w+, 1, 0")
 acc = {n: [] for n in names}
 for fn in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(fn)):

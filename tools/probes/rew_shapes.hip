@@ -6,6 +6,8 @@
 //   2 64 lanes x 12 B (dwordx3)          3 three instructions of 64 lanes x 4 B
 //   4 four steps' rewards together as three full 16-byte instructions (rows of four planes)
 //   5 as 1, issued before the observation rows instead of after them
+//   6 ONE output stream: rows of 46 floats (42 observation values, 3 rewards, the done flag as a float), 11 776 B per
+//     wave-step, contiguous 16-byte vectors -- the same bytes + 3 per env-step, but no second and third stream
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +25,14 @@ __global__ __launch_bounds__(64) void k(float4* obs, float* rew, long long B, in
         const long long row0 = (long long)t * B + env0;
         float4* o = obs + row0 * 42 / 4;
         float* r = rew + row0 * 3;
+        if (VARIANT == 6) {
+            float4* p = obs + row0 * 46 / 4;
+#pragma unroll
+            for (int it = 0; it < 11; ++it) p[it * 64 + lane] = v;
+            if (lane < 32) p[704 + lane] = v;
+            v.x += 1.f;
+            continue;
+        }
         if (VARIANT == 5) { if (lane < 48) reinterpret_cast<float4*>(r)[lane] = v; }
 #pragma unroll
         for (int it = 0; it < 10; ++it) o[it * 64 + lane] = v;
@@ -46,9 +56,9 @@ int main(int argc, char** argv) {
     int T = 24;
     int work = argc > 2 ? atoi(argv[2]) : 0;      // dependent instructions between two steps' stores
     float4* obs; float* rew;
-    CK(hipMalloc(&obs, (size_t)T * B * 168)); CK(hipMalloc(&rew, (size_t)T * B * 12));
+    CK(hipMalloc(&obs, (size_t)T * B * 184)); CK(hipMalloc(&rew, (size_t)T * B * 12));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 6; ++variant) {
+    for (int variant = 0; variant < 7; ++variant) {
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
             const int N = 20;
@@ -60,10 +70,11 @@ int main(int argc, char** argv) {
                 if (variant == 3) hipLaunchKernelGGL(k<3>, g, b, 0, 0, obs, rew, B, T, work);
                 if (variant == 4) hipLaunchKernelGGL(k<4>, g, b, 0, 0, obs, rew, B, T, work);
                 if (variant == 5) hipLaunchKernelGGL(k<5>, g, b, 0, 0, obs, rew, B, T, work);
+                if (variant == 6) hipLaunchKernelGGL(k<6>, g, b, 0, 0, obs, rew, B, T, work);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            double bytes = (double)T * B * (168 + (variant >= 1 ? 12 : 0));
+            double bytes = (double)T * B * (variant == 6 ? 184 : 168 + (variant >= 1 ? 12 : 0));
             if (rep == 2) printf("B=%lld work=%d variant=%d  %.1f us/launch  %.0f GB/s\n", B, work, variant, ms * 1e3 / N, bytes / (ms * 1e-3 / N) / 1e9);
         }
     }

@@ -1,7 +1,7 @@
 # Bench lines for every BASELINE.json config (per-GPU share) plus the batch-size sweep of config 2.
 set -e
 mkdir -p gpurun_out/configs
-run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > gpurun_out/configs/$name.json 2>/dev/null; python - "$name" <<'PY'
+run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --no-configs --no-sustained "$@" > gpurun_out/configs/$name.json 2>/dev/null; python - "$name" <<'PY'
 import json,sys
 n=sys.argv[1]; d=json.load(open('gpurun_out/configs/%s.json'%n))
 r=d['roofline']; s=d.get('step_mode') or {}
