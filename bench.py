@@ -250,9 +250,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-step-mode", action="store_true", help="skip the step_mode and step_auto records")
     ap.add_argument("--no-configs", action="store_true", help="skip the records of the other BASELINE configurations")
     ap.add_argument("--no-sustained", action="store_true", help="skip the sustained figure")
-    ap.add_argument("--layout", default="rows", choices=["rows", "arrays"],
-                    help="output of the episode launches: one packed row per env-step (observation, rewards, done: mpe_episode_rows), "
-                         "where the scenario has that form, or the three arrays obs / rew / done (mpe_episode)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="time every k-th group of 4 episode launches with one HIP event pair (a pair costs ~7 us on the "
                          "stream, so pairs around every launch would throttle submission and inflate the average)")
@@ -335,14 +332,14 @@ def random_actions(torch, env, steps, gen):
     return a
 
 
-def time_episode_launches(torch, env, actions, timed_s, warm_s=0.0, event_every=4, packed=False):
+def time_episode_launches(torch, env, actions, timed_s, warm_s=0.0, event_every=4):
     """Episode launches (on-device reset, its observation, EPISODE steps) of `env` back to back: about `warm_s` seconds
     untimed, then about `timed_s` seconds between two synchronisations, with one HIP event pair around every
     event_every-th group of EVENT_GROUP launches.  Returns launch_ms (HIP events), wall seconds, launches."""
     out = {"o": None}
 
     def launch():
-        out["o"] = env.rollout(actions, out["o"], reset_seed=RESET_SEED, obs0=True, packed=packed)
+        out["o"] = env.rollout(actions, out["o"], reset_seed=RESET_SEED, obs0=True)
 
     for _ in range(2):
         launch()
@@ -375,7 +372,7 @@ def time_episode_launches(torch, env, actions, timed_s, warm_s=0.0, event_every=
     return ms, wall, n
 
 
-def config_record(torch, mpe_hip, dev, name, scenario, B, dtype, kw, timed_s=CONFIG_TIMED_S, warm_s=0.0, layout="rows"):
+def config_record(torch, mpe_hip, dev, name, scenario, B, dtype, kw, timed_s=CONFIG_TIMED_S, warm_s=0.0):
     """One BASELINE configuration as episode launches on this GPU: launch_ms by HIP events, algorithmic bytes of the
     launch, fraction of the 8 TB/s roofline, agent-steps/s by the wall clock of the timed launches."""
     tdt = torch.float32 if dtype == "f32" else torch.float64
@@ -383,14 +380,13 @@ def config_record(torch, mpe_hip, dev, name, scenario, B, dtype, kw, timed_s=CON
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
     actions = random_actions(torch, env, EPISODE, gen)
-    packed = layout == "rows" and env.layout.row_width > 0
-    ms, wall, n = time_episode_launches(torch, env, actions, timed_s, warm_s, packed=packed)
+    ms, wall, n = time_episode_launches(torch, env, actions, timed_s, warm_s)
     lo, s = env.layout, (4 if dtype == "f32" else 8)
     per_step = algorithmic_bytes(env.n_agents, env.n_landmarks, env.n_act, lo.obs_total, s, EPISODE, reads_state=False, reset_obs=True,
                                  hist_rows=lo.n_hist_rows)
     bytes_launch = per_step * B * EPISODE
     return {"name": name, "scenario": scenario, "agents": env.n_agents, "landmarks": env.n_landmarks, "envs": B, "dtype": dtype,
-            "launch": "%s (on-device reset, its observation, %d steps)" % ("mpe_episode_rows" if packed else "mpe_episode", EPISODE), "launch_ms": ms,
+            "launch": "mpe_episode (on-device reset, its observation, %d steps)" % EPISODE, "launch_ms": ms,
             "bytes_per_env_step": per_step, "bytes_per_launch": bytes_launch, "frac": bytes_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "agent_steps_per_s": B * env.n_agents * EPISODE * n / wall, "launches": n, "seconds": wall}
 
@@ -437,7 +433,6 @@ def main():
     # batch of world * B envs would (the draws are keyed by the global env index)
     env = mpe_hip.BatchedEnv(args.scenario, B, dtype=tdt, device=dev, env_base=first_env, **kw)
     A, n_act = env.n_agents, env.n_act
-    packed = args.mode == "rollout" and args.layout == "rows" and env.layout.row_width > 0 and args.episodes_per_launch <= 1
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
@@ -499,7 +494,7 @@ def main():
                     open_pair = None
                 # mpe_episode: on-device reset of every env + n steps in one launch
                 # (with the reset state's observation: everything "obs = env.reset(); 25 x env.step(a)" produces)
-                outs[n] = env.rollout(actions[:n], outs.get(n), reset_seed=RESET_SEED, episodes=k_ep, obs0=True, packed=packed)
+                outs[n] = env.rollout(actions[:n], outs.get(n), reset_seed=RESET_SEED, episodes=k_ep, obs0=True)
                 last["out"] = outs[n]
                 if rec and launches % EVENT_GROUP == EVENT_GROUP - 1 and open_pair is not None:
                     e1 = torch.cuda.Event(enable_timing=True)
@@ -611,7 +606,7 @@ def main():
 
     sustained = None
     if world == 1 and args.mode == "rollout" and K == 1 and not args.no_sustained:
-        ms, wall, n = time_episode_launches(torch, env, actions, SUSTAINED_TIMED_S, SUSTAINED_WARM_S, args.event_every, packed=packed)
+        ms, wall, n = time_episode_launches(torch, env, actions, SUSTAINED_TIMED_S, SUSTAINED_WARM_S, args.event_every)
         sustained = {"launch_ms": ms, "frac": bytes_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "agent_steps_per_s": B * A * EPISODE * n / wall,
                      "launches": n, "seconds": wall, "warmup_seconds": SUSTAINED_WARM_S,
                      "what": "the headline launch after >= %.0f s of untimed launches, timed for >= %.0f s" % (SUSTAINED_WARM_S, SUSTAINED_TIMED_S)}
@@ -623,7 +618,7 @@ def main():
         torch.cuda.empty_cache()
         configs = []
         for name, scn, b_c, dt_c, kw_c in OTHER_CONFIGS:
-            configs.append(config_record(torch, mpe_hip, dev, name, scn, b_c, dt_c, kw_c, layout=args.layout))
+            configs.append(config_record(torch, mpe_hip, dev, name, scn, b_c, dt_c, kw_c))
             torch.cuda.empty_cache()
 
     if rank == 0:
@@ -641,9 +636,7 @@ def main():
             "config": {"workload": "%s A=%d L=%d, %d envs/GPU, %d-step episodes, uniform random int actions, on-device reset each episode"
                                    % (args.scenario, A, lo.n_landmarks, B, EPISODE),
                        "envs_per_gpu": B, "global_envs": world * B, "episode_steps": EPISODE, "reset_seed": RESET_SEED,
-                       "output": ("one array [steps][envs][obs_total + A + 1]: every env-step's observation, rewards and done flag back to back" if packed
-                                  else "three arrays: obs [steps][envs][obs_total], rew [steps][envs][A], done [steps][envs]"),
-                       "launch": {"rollout": ("%s (on-device reset, its observation, %d steps) per launch" % ("mpe_episode_rows" if packed else "mpe_episode", EPISODE)) if K == 1 else
+                       "launch": {"rollout": ("mpe_episode (on-device reset, its observation, %d steps) per launch" % EPISODE) if K == 1 else
                                              ("mpe_episodes: %d x (on-device reset, its observation, %d steps) per launch" % (K, EPISODE)), "step": "mpe_step, 1 step/launch, eager",
                                   "graph": "mpe_step, 1 step/launch, %d launches per hipGraph replay" % EPISODE}[args.mode],
                        "timed_region": "the %d-step request repeated %d times between one pair of barrier + synchronize" % (args.steps, plan["repeats"]),

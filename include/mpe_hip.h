@@ -187,8 +187,7 @@ typedef struct MpeLayout {
     int32_t obs_dim[MPE_MAX_AGENTS];
     int32_t obs_offset[MPE_MAX_AGENTS];
     int32_t n_hist_rows; /* rows of history state kept in the comm buffer (consensus), else 0 */
-    int32_t row_width;   /* values of a packed row of mpe_rollout_rows / mpe_episode_rows: obs_total + A + 1;
-                            0 for scenarios whose launches do not write packed rows */
+    int32_t reserved;
 } MpeLayout;
 
 typedef struct MpeHandle MpeHandle;
@@ -278,22 +277,6 @@ int mpe_rollout(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void
 int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos,
                 void* vel, void* comm, int32_t* aux, void* obs, void* rew, uint8_t* done, int32_t* info_i,
                 void* info_f, void* obs0, int32_t n_steps, mpe_stream_t stream);
-
-/*
- * mpe_rollout / mpe_episode with ONE output array: rows T[n_steps][B][row_width], row_width = obs_total + A + 1
- * (MpeLayout.row_width).  The row of env b at step t is what MultiAgentEnv.step returns for it, back to back: the
- * agents' observations (obs_total values, as in obs), the A rewards (as in rew), and done as 0.0 / 1.0 (0 unless
- * mpe_set_done_bound gave the batch a done callback).  The same values as the three-array form, bit for bit; the
- * array is 16-byte aligned.  One output stream instead of three lets a small batch (one wave per SIMD: 65 536 worlds
- * of simple_spread) store faster than the three-array form: every extra stream of a wave costs more than its bytes
- * there.  Provided for the scenarios whose row_width is not 0 (all in-register scenarios but simple_world_comm,
- * simple_predator_prey and collector), without benchmark outputs and without u_noise / c_noise;
- * MPE_ERR_UNSUPPORTED otherwise.  obs0 T[B][obs_total] as in mpe_episode (NULL to skip).
- */
-int mpe_rollout_rows(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* rows,
-                     int32_t n_steps, mpe_stream_t stream);
-int mpe_episode_rows(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos, void* vel,
-                     void* comm, int32_t* aux, void* rows, void* obs0, int32_t n_steps, mpe_stream_t stream);
 
 /*
  * n_episodes consecutive episodes in one launch: as mpe_episode(h, seed, first_episode + k, ...) for k = 0 ..

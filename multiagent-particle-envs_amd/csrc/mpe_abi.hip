@@ -229,7 +229,6 @@ static void fill_layout(const HostSpec& s, long long n_envs, MpeLayout* lo) {
     }
     lo->n_aux = s.n_aux();
     lo->n_hist_rows = (s.scenario == MPE_SCN_CONSENSUS) ? 10 * A * 4 : 0;
-    lo->row_width = small_packable(s) ? lo->obs_total + A + 1 : 0;
 }
 
 // Validates an MpeSpec and copies it into `s`; errors are recorded for mpe_last_error(NULL).
@@ -383,11 +382,7 @@ static int run(MpeHandle* h, int mode, const StepArgs& args, mpe_stream_t stream
         return fail(h, MPE_ERR_INVALID, "%s: comm must not be NULL for a scenario with speaking agents or a history", who);
     if (h->spec.scenario == MPE_SCN_CONSENSUS && a.info_i != nullptr)
         return fail(h, MPE_ERR_UNSUPPORTED, "%s: consensus has no benchmark outputs (its benchmark_data is constant)", who);
-    if (a.packed) {
-        if (h->layout.row_width == 0) return fail(h, MPE_ERR_UNSUPPORTED, "%s: this scenario's launches do not write packed rows (MpeLayout.row_width is 0)", who);
-        if (a.noise.enabled) return fail(h, MPE_ERR_UNSUPPORTED, "%s: packed rows are not written for worlds with u_noise / c_noise", who);
-        if (!a.actions) return fail(h, MPE_ERR_INVALID, "%s: actions must not be NULL", who);
-    } else if (mode != 2 && (!a.actions || !a.rew || !a.done)) return fail(h, MPE_ERR_INVALID, "%s: actions, rew and done must not be NULL", who);
+    if (mode != 2 && (!a.actions || !a.rew || !a.done)) return fail(h, MPE_ERR_INVALID, "%s: actions, rew and done must not be NULL", who);
     if (mode == 1 && a.n_steps < 1) return fail(h, MPE_ERR_INVALID, "%s: n_steps must be >= 1", who);
     if (a.info_f && !a.info_i) return fail(h, MPE_ERR_INVALID, "%s: info_f requires info_i", who);
     if (a.info_i && h->layout.n_info_i == 0) return fail(h, MPE_ERR_INVALID, "%s: this scenario has no benchmark_data; info_i must be NULL", who);
@@ -488,24 +483,6 @@ int mpe_episode(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* ac
     a.obs0 = obs0;
     if (h) a.reset = ResetArgs{1, seed, episode, landmark_limit(h->spec)};
     return run(h, 1, a, stream, "mpe_episode");
-}
-
-int mpe_rollout_rows(MpeHandle* h, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux, void* rows, int32_t n_steps,
-                     mpe_stream_t stream) {
-    StepArgs a{actions, pos, vel, comm, rows, nullptr, nullptr, nullptr, nullptr, n_steps};
-    a.aux = aux;
-    a.packed = 1;
-    return run(h, 1, a, stream, "mpe_rollout_rows");
-}
-
-int mpe_episode_rows(MpeHandle* h, uint64_t seed, uint64_t episode, const int32_t* actions, void* pos, void* vel, void* comm, int32_t* aux,
-                     void* rows, void* obs0, int32_t n_steps, mpe_stream_t stream) {
-    StepArgs a{actions, pos, vel, comm, rows, nullptr, nullptr, nullptr, nullptr, n_steps};
-    a.aux = aux;
-    a.obs0 = obs0;
-    a.packed = 1;
-    if (h) a.reset = ResetArgs{1, seed, episode, landmark_limit(h->spec)};
-    return run(h, 1, a, stream, "mpe_episode_rows");
 }
 
 int mpe_episodes(MpeHandle* h, uint64_t seed, uint64_t first_episode, int32_t n_episodes, int32_t steps_per_episode, const int32_t* actions,

@@ -104,7 +104,6 @@ struct StepArgs {
     NoiseArgs noise;          // enabled only for worlds with u_noise / c_noise
     unsigned long long env_base;      // global index of the batch's first env (mpe_set_env_base): keys every on-device draw
     double done_bound;                // > 0: done_callback "an agent is outside [-bound, bound]^2" (mpe_set_done_bound); 0: none
-    int packed;                       // rollout launches: obs is T[n_steps][B][obs_total + A + 1] (observation, rewards, done); rew / done unused
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112
@@ -116,7 +115,6 @@ inline double landmark_limit(const HostSpec& s) {
 
 // small in-register scenarios (mpe_small.hip); mode: 0 step, 1 rollout, 2 observe, 3 Scenario.post_step alone (pos, aux)
 bool small_supported(const HostSpec& s);
-bool small_packable(const HostSpec& s);      // the scenario's rollout launches can write packed rows (StepArgs::packed)
 hipError_t launch_small(const HostSpec& s, long long n_envs, int dtype, int mode, const StepArgs& a, hipStream_t st);
 
 }  // namespace mpe

@@ -63,9 +63,6 @@ struct CfgBase {
     // other scenarios whose row leaves in one flush; the scenarios of the cooperative passes, whose stores are spread
     // over the step, lose with them (collector 44 -> 52 us, simple_predator_prey 54 -> 60 us) and keep plain stores.
     static constexpr bool NT_STEP = true;
-    // PACKABLE: rollout launches can write one packed row per world-step (observation, rewards, done) instead of three
-    // arrays: the scenarios whose observation row leaves in a single flush
-    static constexpr bool PACKABLE = true;
     // stage_packed(): the cooperative passes' staging area without its padding word (row stride 2E + 2A, a multiple of 4
     //   values), written as 16-byte vectors; for a scenario that needs the 256 bytes to fit eight workgroups a CU
     template <typename T> __host__ __device__ static constexpr bool stage_packed() { return false; }
@@ -339,7 +336,6 @@ struct WorldCommCfg : CfgBase {
     // one-wave workgroups per CU; two halves (25 KB) for six; a third (16.6 KB, 18 KB with the reward tile) for the
     // eight that two waves per SIMD need.  The episode kernel fits 256 registers with 6 steps' action words per fetch
     // (2 registers spilled) and runs two rounds of 2 048 resident waves at 262 144 worlds instead of four of 1 024.
-    static constexpr bool PACKABLE = false;     // its row leaves in column chunks
     static constexpr int OBS_CHUNKS = 3, CHUNK_MAX = OBS_TOTAL / OBS_CHUNKS, CHUNK_MIN = OBS_TOTAL / OBS_CHUNKS;
     __host__ __device__ __forceinline__ static constexpr int chunk_width(int) { return OBS_TOTAL / OBS_CHUNKS; }
     __host__ __device__ __forceinline__ static constexpr int chunk_offset(int c) { return c * (OBS_TOTAL / OBS_CHUNKS); }
@@ -824,7 +820,6 @@ struct PredatorPreyCfg : CfgBase {
     __host__ __device__ __forceinline__ static constexpr int rep(int e) { return e < N_ADV ? 0 : (e < A ? N_ADV : (e == BARRIER ? BARRIER : (e < FOREST0 ? FOOD0 : FOREST0))); }
     // a 64 x 315 tile (80 KB in float32) would leave one wave per CU: 8 whole rows at a time, the lanes regrouped
     // as 8 worlds x 7 agents (8 lanes idle during the observation)
-    static constexpr bool PACKABLE = false;
     static constexpr bool NT_STEP = false;      // see CfgBase
     static constexpr bool OBS_COOP = true;
     // Two waves per SIMD (all 2 048 waves of a 131 072-world launch resident at once): 256 registers, eight 20 KB
@@ -1169,7 +1164,6 @@ struct CollectorCfg : CfgBase {
     // sorted(zip(distance, index)): ascending distance, ties by index (collector.py:272-278)
     template <typename T> __device__ static __forceinline__ bool after(T ka, int ia, T kb, int ib) { return ka > kb || (ka == kb && ia > ib); }
 
-    static constexpr bool PACKABLE = false;
     static constexpr bool NT_STEP = false;      // see CfgBase
     static constexpr bool OBS_COOP = true;
 

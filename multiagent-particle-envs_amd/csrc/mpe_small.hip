@@ -20,12 +20,6 @@ bool small_supported(const HostSpec& s) {
            s.scenario == MPE_SCN_PREDATOR_PREY || s.scenario == MPE_SCN_COLLECTOR;
 }
 
-// (the scenarios whose Cfg::PACKABLE is true: every in-register scenario but simple_world_comm, whose row leaves in
-// column chunks, and the two of the cooperative passes)
-bool small_packable(const HostSpec& s) {
-    return small_supported(s) && s.scenario != MPE_SCN_WORLD_COMM && s.scenario != MPE_SCN_PREDATOR_PREY && s.scenario != MPE_SCN_COLLECTOR;
-}
-
 hipError_t launch_small(const HostSpec& s, long long B, int dtype, int mode, const StepArgs& a, hipStream_t st) {
     const bool f64 = dtype == MPE_F64;
     switch (s.scenario) {

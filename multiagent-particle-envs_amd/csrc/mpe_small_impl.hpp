@@ -11,8 +11,6 @@
 // A workgroup is a single 64-lane wave: the LDS tiles are private to the wave, so the
 // __syncthreads() below are plain LDS waits, not hardware barriers.
 #pragma once
-#include <type_traits>
-
 #include "mpe_scenarios.hpp"
 #include "mpe_launch.hpp"
 
@@ -158,14 +156,7 @@ namespace mpe {
 //   reset_kernel would (Scenario.reset_world), so an episode is a single launch.
 // NOISE: the world has agents with u_noise / c_noise (its own instantiation: the generator is an out-of-line
 //   call, and a kernel with a call site pays for the calling convention in registers on every path).
-// PACKED (rollout launches, no benchmark outputs): ONE output stream.  obs_g is then T[n_steps][B][OT + A + 1], the row
-//   of a world-step being its observation, its A rewards and its done flag (0.0 / 1.0) back to back; rew_g and done_g
-//   are not written.  A wave's 64 rows are one contiguous block of whole 128-byte lines (256 * row values bytes).  At
-//   65 536 worlds, one wave per SIMD, every further store stream of a wave costs more than its bytes -- without the
-//   reward rows (6 % of the bytes) the episode launch is 11 % shorter, and rocprofv3 counters put the difference in
-//   the waves' own waiting at the store issue (SQ_WAIT_ANY -26 %, the vector L1's pending stalls -12 %), not in the
-//   fabric (DRAM credit stalls -5 %) -- while the same bytes inside the observation rows' stream cost their share.
-template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false, bool PACKED = false>
+template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false>
 __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOISE) ? Cfg::template waves_per_simd<T>() : 1) void small_kernel(const SmallParams<T, Cfg::E, Cfg::A> p, const ResetArgs rs, const AutoArgs au,
                                                    const long long env_begin, const long long env_end,
                                                    const int* __restrict__ actions, T* __restrict__ pos_g,
@@ -185,12 +176,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
     constexpr bool COOP = Cfg::OBS_COOP;                                 // whole rows of 8 worlds per pass, lanes = worlds x agents
     static_assert(!COOP || (EPW == 64 && A <= 8 && !Cfg::OBS_LOOP && RP == 0), "cooperative passes regroup a full wave as 8 worlds x up to 8 agents");
     constexpr int TROWS = COOP ? 8 : (RP > 0 ? EPW / RP : EPW);
-    static_assert(!PACKED || (MODE == MODE_ROLLOUT && !INFO && Cfg::OBS_CHUNKS == 1 && !COOP && RP == 0 && !Cfg::OBS_LOOP),
-                  "packed rows: rollout launches of the scenarios whose row leaves in one flush");
-    constexpr int PW = OT + A + 1;                                       // packed row: observation, rewards, done
-    constexpr bool LINP = ((PW * (int)sizeof(T) / 4) % 16) != 0;
-    using ObsTile0 = Tile<T, (COOP ? OT : OW), (COOP ? true : LIN), TROWS>;      // rows of observations only
-    using ObsTile = std::conditional_t<PACKED, Tile<T, PW, LINP, TROWS>, ObsTile0>;
+    using ObsTile = Tile<T, (COOP ? OT : OW), (COOP ? true : LIN), TROWS>;
     using CoopStage = StagedRows<T, E, A, Cfg::template stage_packed<T>()>;
     using RewTile = Tile<T, A, true, EPW>;
     using IiTile = Tile<int, NI, true, EPW>;
@@ -489,11 +475,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
         const bool want_score = !pre && ((MODE != MODE_OBSERVE) || (rew_g != nullptr));   // observe: rewards on request
         bool finished = false;
         if (EPW == 64 || lane < EPW) {
-            // the agents' rewards: a row of the reward tile, or (packed rows) the columns behind the observation
-            T* const rrow = PACKED ? ObsTile::row(tile_obs, tile_lane) + OT : RewTile::row(tile_rew, tile_lane);
+            T* const rrow = RewTile::row(tile_rew, tile_lane);
             if (want_score)
                 Cfg::template score<T>(pos, comm, aux, p, rrow, want_info, IiTile::row(tile_ii, tile_lane), IfTile::row(tile_if, tile_lane));
-            if (PACKED && want_score) rrow[A] = outside ? T(1) : T(0);      // done: no callback (environment.py:143-146) or the bound
             if (Cfg::SHARED && MODE != MODE_OBSERVE && !pre) {
                 // collaborative world: step hands every agent np.sum(reward_n) (environment.py:103-105);
                 // numpy adds fewer than 8 values left to right
@@ -545,18 +529,17 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                     }
                 }
             }
-            if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP)
-                Cfg::template observe<T>(pos, vel, comm, aux, p, (PACKED && pre) ? ObsTile0::row(tile_obs, tile_lane) : ObsTile::row(tile_obs, tile_lane));
+            if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) Cfg::template observe<T>(pos, vel, comm, aux, p, ObsTile::row(tile_obs, tile_lane));
         }
         STAMP_T(31);
         const long long row0 = (long long)t * B + env0;
-        T* const obs_dst = pre ? obs0_g + (ep_idx * B + env0) * OT : obs_g + row0 * (PACKED ? PW : OT);
+        T* const obs_dst = pre ? obs0_g + (ep_idx * B + env0) * OT : obs_g + row0 * OT;
         auto flush_small = [&]() {
             // (a kernel on a tight register budget: an opaque copy of the lane keeps the flushes' addresses per-step
             // work; hoisted out of the step loop they are spilled, and every reload waits for the wave's older stores)
             int lane_f = lane;
             if constexpr (MODE == MODE_ROLLOUT && FULL && !INFO && !NOISE && Cfg::template waves_per_simd<T>() > 1) asm volatile("" : "+v"(lane_f));
-            if (want_score && !PACKED) {
+            if (want_score) {
 #ifdef MPE_ABLATE_REW
                 // Diagnostic build only (tools/pmc_headline.py): the reward rows stay computed but are not stored, behind
                 // a condition the compiler cannot fold, to price that output stream with counters.
@@ -684,10 +667,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
         if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, p.env_base + (unsigned long long)b);
         __syncthreads();
         STAMP_T(41);
-        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) {
-            if (PACKED && pre) ObsTile0::template flush<FULL, NT>(tile_obs, obs_dst, lane, nvalid);      // the reset observation: rows of OT values
-            else ObsTile::template flush<FULL, NT>(tile_obs, obs_dst, lane, nvalid);
-        }
+        if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) ObsTile::template flush<FULL, NT>(tile_obs, obs_dst, lane, nvalid);
         if constexpr (!COOP) flush_small();
         if (MODE == MODE_ROLLOUT) {
             if (t >= 0 && t < 28) STAMP(2 + t);
@@ -785,11 +765,11 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     return p;
 }
 
-template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false, bool PACKED = false>
+template <typename T, class Cfg, bool CLAMP, int MODE, bool FULL, bool INFO, int EPW, bool NOISE = false>
 static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_begin, long long env_end, const StepArgs& a, hipStream_t st) {
     if (env_end <= env_begin) return;
     const dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
-    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW, NOISE, PACKED>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
+    hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW, NOISE>), grid, block, 0, st, p, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,
                        (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, a.aux, (T*)a.obs0, a.noise, a.n_steps);
 }
 
@@ -804,13 +784,6 @@ static void launch_epw(const SmallParams<T, Cfg::E, Cfg::A>& p, long long B, con
         }
     }
     const long long n_full = ((B & 3) == 0) ? (B / EPW) * EPW : 0;
-    if constexpr (MODE == MODE_ROLLOUT && !INFO && Cfg::PACKABLE) {
-        if (a.packed) {     // one output stream (mpe_rollout_rows / mpe_episode_rows)
-            launch_range<T, Cfg, CLAMP, MODE, true, INFO, EPW, false, true>(p, 0, n_full, a, st);
-            launch_range<T, Cfg, CLAMP, MODE, false, INFO, (EPW < 64 ? EPW : 64), false, true>(p, n_full, B, a, st);
-            return;
-        }
-    }
     launch_range<T, Cfg, CLAMP, MODE, true, INFO, EPW>(p, 0, n_full, a, st);
     launch_range<T, Cfg, CLAMP, MODE, false, INFO, (EPW < 64 ? EPW : 64)>(p, n_full, B, a, st);
 }

@@ -45,7 +45,7 @@ class MpeLayout(C.Structure):
         ("n_speakers", C.c_int32), ("n_act", C.c_int32), ("obs_total", C.c_int32),
         ("n_info_i", C.c_int32), ("n_info_f", C.c_int32), ("state_env_major", C.c_int32), ("n_aux", C.c_int32),
         ("obs_dim", C.c_int32 * MAX_AGENTS), ("obs_offset", C.c_int32 * MAX_AGENTS),
-        ("n_hist_rows", C.c_int32), ("row_width", C.c_int32),
+        ("n_hist_rows", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -68,10 +68,6 @@ EXPORTS = {
     "mpe_rollout": (C.c_int, [C.c_void_p] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
     # (handle, seed, episode, actions, pos, vel, comm, aux, obs, rew, done, info_i, info_f, obs0, n_steps, stream)
     "mpe_episode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 11 + [C.c_int32, C.c_void_p]),
-    # (handle, actions, pos, vel, comm, aux, rows, n_steps, stream)
-    "mpe_rollout_rows": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]),
-    # (handle, seed, episode, actions, pos, vel, comm, aux, rows, obs0, n_steps, stream)
-    "mpe_episode_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]),
     # (handle, seed, first_episode, n_episodes, steps_per_episode, actions, pos, vel, comm, aux, obs, rew, done, info_i, info_f, obs0, stream)
     "mpe_episodes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + [C.c_void_p]),
     # (handle, pos, vel, comm, aux, obs, rew, info_i, info_f, stream)

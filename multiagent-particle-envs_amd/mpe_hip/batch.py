@@ -229,22 +229,17 @@ class BatchedEnv:
                                                    p["info_i"], p["info_f"], self._stream()))
         return self.obs, self.rew, self.done, (self.info_i, self.info_f)
 
-    def rollout(self, actions, out=None, reset_seed=None, episodes=1, obs0=False, packed=False):
+    def rollout(self, actions, out=None, reset_seed=None, episodes=1, obs0=False):
         """``T`` steps in one launch for pre-computed actions ``[T, B, n_act]``.  Returns a dict of
         ``[T, ...]`` tensors (pass the previous result as ``out`` to reuse its buffers).  With
         ``reset_seed`` every env is first reset on device inside the same launch (one episode per
         launch, like ``reset(seed, observe=False)`` followed by ``rollout``); with ``episodes`` = K > 1
         the T steps are K consecutive episodes of T / K steps, each starting with its own reset.  With
         ``obs0`` the launch also returns the observation of every reset state, ``out["obs0"]``
-        ``[K, B, obs_total]`` (what ``reset()`` returns).  With ``packed`` the launch writes ONE array, ``out["rows"]``
-        ``[T, B, obs_total + A + 1]`` -- every env-step's observation, rewards and done flag (0.0 / 1.0) back to back,
-        the faster layout for small batches -- and ``out["obs"]`` / ``out["rew"]`` / ``out["done"]`` are column views
-        into it (same values as the three-array form; not with ``episodes`` > 1, ``info`` or noise)."""
+        ``[K, B, obs_total]`` (what ``reset()`` returns)."""
         T = int(actions.shape[0])
         a = self._actions(actions, (T,))
         lo, B = self.layout, self.n_envs
-        if packed:
-            return self._rollout_rows(a, T, out, reset_seed, episodes, obs0)
         if obs0 and reset_seed is None:
             raise ValueError("obs0 is the observation of an on-device reset: pass reset_seed")
         if out is None or out["obs"].shape[0] != T or (obs0 and (out.get("obs0") is None or out["obs0"].shape[0] != episodes)):
@@ -270,30 +265,6 @@ class BatchedEnv:
             _lib.check(self._h, self._lib.mpe_episode(self._h, int(reset_seed), self._episode, _ptr(a), p["pos"], p["vel"], p["comm"],
                                                       p["aux"], _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["info_i"]),
                                                       _ptr(out["info_f"]), first, T, self._stream()))
-            self._episode += 1
-        return out
-
-    def _rollout_rows(self, a, T, out, reset_seed, episodes, obs0):
-        lo, B, A = self.layout, self.n_envs, self.n_agents
-        if lo.row_width == 0:
-            raise ValueError("scenario %r does not write packed rows" % self.spec.name)
-        if episodes != 1 or self.info_i is not None:
-            raise ValueError("packed rows: one episode per launch, no benchmark outputs")
-        if obs0 and reset_seed is None:
-            raise ValueError("obs0 is the observation of an on-device reset: pass reset_seed")
-        if out is None or out.get("rows") is None or out["rows"].shape[0] != T or (obs0 and out.get("obs0") is None):
-            rows = torch.empty(T, B, lo.row_width, dtype=self.dtype, device=self.device)
-            out = {"rows": rows, "obs": rows[..., :lo.obs_total], "rew": rows[..., lo.obs_total:lo.obs_total + A],
-                   "done": rows[..., lo.obs_total + A], "info_i": None, "info_f": None,
-                   "obs0": torch.empty(1, B, lo.obs_total, dtype=self.dtype, device=self.device) if obs0 else None}
-        first = _ptr(out.get("obs0")) if obs0 else None
-        p = self._p
-        if reset_seed is None:
-            _lib.check(self._h, self._lib.mpe_rollout_rows(self._h, _ptr(a), p["pos"], p["vel"], p["comm"], p["aux"], _ptr(out["rows"]), T,
-                                                           self._stream()))
-        else:
-            _lib.check(self._h, self._lib.mpe_episode_rows(self._h, int(reset_seed), self._episode, _ptr(a), p["pos"], p["vel"], p["comm"],
-                                                           p["aux"], _ptr(out["rows"]), first, T, self._stream()))
             self._episode += 1
         return out
 

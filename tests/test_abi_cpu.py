@@ -35,7 +35,6 @@ def test_struct_mirrors_match_header_sizes():
     # MpeSpec: 4 int32 + 4 double + 9 pointers + 2 int32 + 7 pointers + 2 int32 + 3 pointers ; MpeLayout: int64 + 10 int32 + 2 * 64 int32
     assert C.sizeof(_lib.MpeSpec) == 16 + 32 + 9 * 8 + 8 + 7 * 8 + 8 + 3 * 8
     assert C.sizeof(_lib.MpeLayout) == 8 + 10 * 4 + 2 * 64 * 4 + 8
-    assert _lib.MpeLayout.row_width.offset == C.sizeof(_lib.MpeLayout) - 4
 
 
 def test_create_rejects_bad_arguments_without_a_gpu():

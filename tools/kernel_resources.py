@@ -22,6 +22,6 @@ for k in notes.split("- .agpr_count:")[1:]:
 names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.strip().split("\n")
 print("scenario, CLAMP, MODE, FULL, INFO, EPW, NOISE | agpr vgpr(total) vgpr_spill sgpr_spill lds_bytes")
 for r, d in sorted(zip(rows, names), key=lambda x: x[1]):
-    m = re.match(r"void mpe::small_kernel<(\w+), mpe::(\w+)(?:<[^>]*>)?, (\w+), (\d), (\w+), (\w+), (\d+), (\w+)>", d)
+    m = re.match(r"void mpe::small_kernel<(\w+), mpe::(\w+)(?:<[^>]*>)?, (\w+), (\d), (\w+), (\w+), (\d+), (\w+)(?:, (\w+))?>", d)
     if m and want in m.group(2):
-        print(", ".join(m.groups()), "|", *r[1:])
+        print(", ".join(g for g in m.groups() if g is not None), "|", *r[1:])
