@@ -43,6 +43,9 @@ constexpr int WPG = 32;          // worlds per workgroup
 constexpr int NT = WPG * CA;     // its threads: thread = world * 6 + agent, three full waves
 constexpr int XS = WPG + 1;      // row stride of the exchange area (odd: a wave's writes spread over the banks)
 constexpr int ROW = CA * COBS;   // observation values of one world-step
+#ifndef MPE_NT_STEP_DEFAULT
+#define MPE_NT_STEP_DEFAULT true
+#endif
 
 // MODE 0: mpe_step / mpe_step_auto, 1: mpe_rollout / mpe_episode(s), 2: mpe_observe
 // NOISE: agents with u_noise (its own instantiation: the generator is an out-of-line call)
@@ -65,6 +68,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
                                                        uint8_t* __restrict__ done_g, T* __restrict__ obs0_g, int n_steps) {
     // Every lane's 80 values sit PAD apart: with the rows back to back (80 dwords) the lanes' 16-byte writes fall on
     // 2 of the 8 four-bank groups, a 32-way conflict; at 84 they spread over all of them.
+    constexpr bool NT_STORES = MODE == 0 && MPE_NT_STEP_DEFAULT;     // a launch of one step stores non-temporally (mpe_math.hpp: put)
     constexpr int PAD = COBS + 16 / (int)sizeof(T);
     // agent-rows a wave's tile holds: all 64 of its lanes' rows in float32 (21 KB a wave, 66 KB a workgroup: two
     // workgroups per CU, which is what the registers allow anyway), half of them at a time in float64
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
 #pragma unroll
                     for (int i = 0; i < CA * 4 * WPG / NT; ++i) {
                         const int j = i * NT + tid, r = j / WPG, wj = j - r * WPG;
-                        if (wj < nvalid) put<MODE == 0>(&hist_g[(long long)(head * CA * 4 + r) * B + env0 + wj], xch[r * XS + wj]);
+                        if (wj < nvalid) put<NT_STORES>(&hist_g[(long long)(head * CA * 4 + r) * B + env0 + wj], xch[r * XS + wj]);
                     }
                 } else if (valid) {
                     hist_g[hrow(head, 0)] = pos.x; hist_g[hrow(head, 1)] = pos.y;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
                 reset_world(ResetArgs{1, au.seed, (unsigned long long)epi, au.landmark_lim, 0, au.env_base}, finished, 0);
             }
             if (valid) {
-                put<MODE == 0>(&rew_g[row * CA + tid], out);        // 32 worlds x 6 rewards: six whole lines
+                put<NT_STORES>(&rew_g[row * CA + tid], out);        // 32 worlds x 6 rewards: six whole lines
                 // no done callback (environment.py:143-146); mpe_step_auto flags the step that reaches its time limit
                 if (MODE == 0 && a == 0) done_g[row + w] = (finished || outside) ? 1 : 0;
                 if (MODE == 1 && a == 0 && p.done_bound > T(0)) done_g[row + w] = outside ? 1 : 0;
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
 #pragma unroll 5
                 for (int i = 0; i < NVT / 64; ++i) {
                     const int g = i * 64 + lane, ar = g / NVA, j = g - ar * NVA;
-                    if (row0 + ar < rows_valid) put<MODE == 0>(&dst[g], *reinterpret_cast<const VT*>(my_tile + ar * PAD + j * VEC));
+                    if (row0 + ar < rows_valid) put<NT_STORES>(&dst[g], *reinterpret_cast<const VT*>(my_tile + ar * PAD + j * VEC));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
             for (int i = 0; i < CA * 4 * WPG / NT; ++i) {
                 const int j = i * NT + tid, r = j / WPG, wj = j - r * WPG, c = r & 3;
                 T* const dst = (c < 2) ? pos_g : vel_g;
-                if (wj < nvalid) put<MODE == 0>(&dst[(long long)(2 * (r >> 2) + (c & 1)) * B + env0 + wj], xch[r * XS + wj]);
+                if (wj < nvalid) put<NT_STORES>(&dst[(long long)(2 * (r >> 2) + (c & 1)) * B + env0 + wj], xch[r * XS + wj]);
             }
             // every world's own head: a time-limit reset inside the launch (mpe_step_auto) puts the worlds it resets
             // back to slot 0 while their neighbours advance, so the heads may differ by now

@@ -12,6 +12,10 @@ namespace mpe {
 
 constexpr int SMALL_MAX_WALLS = 4;
 
+#ifndef MPE_NT_STEP_DEFAULT
+#define MPE_NT_STEP_DEFAULT true       // (a diagnostic build may switch the single steps' non-temporal stores off: -DMPE_NT_STEP_DEFAULT=false)
+#endif
+
 template <typename T, int E, int A>
 struct SmallParams {
     T size[E];
@@ -62,7 +66,7 @@ struct CfgBase {
     // scenario (one launch per step under a hipGraph): 6.0 -> 5.1 us for simple_spread at 65 536 worlds and 6-18 % for the
     // other scenarios whose row leaves in one flush; the scenarios of the cooperative passes, whose stores are spread
     // over the step, lose with them (collector 44 -> 52 us, simple_predator_prey 54 -> 60 us) and keep plain stores.
-    static constexpr bool NT_STEP = true;
+    static constexpr bool NT_STEP = MPE_NT_STEP_DEFAULT;
     // stage_packed(): the cooperative passes' staging area without its padding word (row stride 2E + 2A, a multiple of 4
     //   values), written as 16-byte vectors; for a scenario that needs the 256 bytes to fit eight workgroups a CU
     template <typename T> __host__ __device__ static constexpr bool stage_packed() { return false; }
