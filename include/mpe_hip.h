@@ -316,6 +316,15 @@ int mpe_set_noise(MpeHandle* h, uint64_t seed, const void* draws);
 int mpe_noise_state(MpeHandle* h, int set, uint64_t* seed, uint64_t* step);
 
 /*
+ * Whether the stepping launches (mpe_step, mpe_step_auto, mpe_rollout, mpe_episode(s)) apply the scenario's post_step
+ * after the callbacks: MultiAgentEnv(post_step_callback=scenario.post_step) (enabled = 1, the default) or
+ * MultiAgentEnv(post_step_callback=None) (enabled = 0), which is what make_env builds (make_env.py:36-43 passes no
+ * post_step_callback, so environment.py:107-108 calls none): the world then steps and is observed but nothing is ever
+ * picked up, handed over or respawned.  MPE_ERR_UNSUPPORTED for scenarios without a post_step.
+ */
+int mpe_set_post_step(MpeHandle* h, int enabled);
+
+/*
  * Scenario.post_step alone (simple_predator_prey.py:83-107, collector.py:84-110), what MultiAgentEnv.step
  * calls as post_step_callback after the observation / reward callbacks (environment.py:107-108): pick-ups,
  * hand-overs and respawns exactly as mpe_step applies them, for a caller that steps the world and

@@ -23,6 +23,7 @@ struct MpeHandle {
     const void* noise_draws;
     unsigned long long env_base;    // global index of the handle's first env (mpe_set_env_base), 0 by default
     double done_bound;              // > 0: the batch's done predicate (mpe_set_done_bound); 0: no done callback
+    int skip_post_step;             // 1: stepping launches leave the scenario's post_step out (mpe_set_post_step(h, 0))
     char err[512];
 };
 
@@ -372,6 +373,7 @@ static int run(MpeHandle* h, int mode, const StepArgs& args, mpe_stream_t stream
     StepArgs a = args;
     a.env_base = a.reset.env_base = a.au.env_base = h->env_base;
     a.done_bound = h->done_bound;
+    a.skip_post_step = h->skip_post_step;
     if (mode != 2 && h->spec.any_noise()) {
         a.noise = NoiseArgs{1, h->spec.noise_stride(), h->noise_draws, h->noise_seed, h->noise_step, h->env_base};
         if (((uintptr_t)h->noise_draws & (h->dtype == MPE_F64 ? 7u : 3u)) != 0) return fail(h, MPE_ERR_INVALID, "%s: misaligned noise draws", who);
@@ -414,6 +416,14 @@ int mpe_set_env_base(MpeHandle* h, uint64_t env_base) {
     if (!h) return MPE_ERR_INVALID;
     if (env_base > 0xffffffffffffull) return fail(h, MPE_ERR_INVALID, "mpe_set_env_base: env_base must be below 2^48");
     h->env_base = env_base;
+    return MPE_OK;
+}
+
+int mpe_set_post_step(MpeHandle* h, int enabled) {
+    if (!h) return MPE_ERR_INVALID;
+    if (h->spec.scenario != MPE_SCN_PREDATOR_PREY && h->spec.scenario != MPE_SCN_COLLECTOR)
+        return fail(h, MPE_ERR_UNSUPPORTED, "mpe_set_post_step: only simple_predator_prey and collector define post_step");
+    h->skip_post_step = enabled ? 0 : 1;
     return MPE_OK;
 }
 

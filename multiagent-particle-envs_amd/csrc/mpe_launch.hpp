@@ -104,6 +104,7 @@ struct StepArgs {
     NoiseArgs noise;          // enabled only for worlds with u_noise / c_noise
     unsigned long long env_base;      // global index of the batch's first env (mpe_set_env_base): keys every on-device draw
     double done_bound;                // > 0: done_callback "an agent is outside [-bound, bound]^2" (mpe_set_done_bound); 0: none
+    int skip_post_step;               // 1: a scenario's post_step is not applied by the stepping launches (mpe_set_post_step(h, 0))
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112

@@ -664,7 +664,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
         }
         // post_step_callback runs after the callbacks (environment.py:107-108); a world that was just
         // reset starts its episode untouched
-        if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && (EPW == 64 || lane < EPW)) Cfg::post_step(pos, aux, p, p.env_base + (unsigned long long)b);
+        if (Cfg::DYNAMIC && MODE != MODE_OBSERVE && !pre && !finished && p.skip_post_step == 0 && (EPW == 64 || lane < EPW))
+            Cfg::post_step(pos, aux, p, p.env_base + (unsigned long long)b);
         __syncthreads();
         STAMP_T(41);
         if constexpr (Cfg::OBS_CHUNKS == 1 && RP == 0 && !COOP) ObsTile::template flush<FULL, NT>(tile_obs, obs_dst, lane, nvalid);
@@ -753,6 +754,7 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     p.n_envs = n_envs;
     p.env_base = env_base;
     p.done_bound = T(0);
+    p.skip_post_step = 0;
     for (int e = 0; e < Cfg::E; ++e) p.size_d[e] = s.size[e];
     for (int i = 0; i < Cfg::A; ++i) { p.u_noise[i] = (T)s.u_noise[i]; p.c_noise[i] = (T)s.c_noise[i]; }
     for (int i = 0; i < Cfg::A; ++i) { p.force_scale[i] = (T)s.force_scale[i]; p.ghost[i] = s.ghost[i]; }
@@ -806,6 +808,7 @@ template <typename T, class Cfg, bool CLAMP>
 static hipError_t launch_cfg(const HostSpec& s, long long B, int mode, const StepArgs& a, hipStream_t st) {
     auto p = make_params<T, Cfg>(s, B, a.env_base);
     p.done_bound = (T)a.done_bound;
+    p.skip_post_step = a.skip_post_step;
     const bool info = a.info_i != nullptr;
     switch (mode) {
         case MODE_STEP:

@@ -73,6 +73,8 @@ EXPORTS = {
     # (handle, pos, vel, comm, aux, obs, rew, info_i, info_f, stream)
     "mpe_observe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]),
     "mpe_post_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # (handle, enabled)
+    "mpe_set_post_step": (C.c_int, [C.c_void_p, C.c_int]),
     # (handle, bound)
     "mpe_set_done_bound": (C.c_int, [C.c_void_p, C.c_double]),
     # (handle, env_base)

@@ -37,7 +37,7 @@ class BatchedEnv:
     """
 
     def __init__(self, scenario, n_envs, dtype=torch.float32, device="cuda:0", info=False, max_episode_steps=None, seed=0,
-                 scripted=None, env_base=0, done_bound=None, **spec_kw):
+                 scripted=None, env_base=0, done_bound=None, post_step=True, **spec_kw):
         self.spec = scenario if isinstance(scenario, WorldSpec) else make_spec(scenario, **spec_kw)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -65,6 +65,11 @@ class BatchedEnv:
         self.done_bound = None if done_bound is None else float(done_bound)
         if self.done_bound is not None:
             _lib.check(h, self._lib.mpe_set_done_bound(h, self.done_bound))
+        # post_step=False: the scenario's post_step is left out of the step, as in MultiAgentEnv(post_step_callback=None)
+        # (what the reference's make_env builds, make_env.py:36-43); only scenarios that have one take the switch
+        self.post_step_enabled = bool(post_step)
+        if not self.post_step_enabled:
+            _lib.check(h, self._lib.mpe_set_post_step(h, 0))
         lo = _lib.MpeLayout()
         _lib.check(h, self._lib.mpe_layout(h, C.byref(lo)))
         self.layout = lo
@@ -337,7 +342,7 @@ class BatchedEnv:
             v = getattr(self.spec, f.name)
             h.update(f.name.encode() + b"=")
             h.update(np.asarray(v, dtype=np.float64).tobytes() if isinstance(v, np.ndarray) else repr(v).encode())
-        h.update(repr((self.max_episode_steps, self.env_major, self.env_base, self.done_bound)).encode())
+        h.update(repr((self.max_episode_steps, self.env_major, self.env_base, self.done_bound, self.post_step_enabled)).encode())
         return h.hexdigest()[:32]
 
     def _noise_state(self, put=None):

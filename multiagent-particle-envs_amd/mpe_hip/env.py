@@ -64,11 +64,15 @@ class MultiAgentEnv:
         cbs = [cb for cb in (reset_callback, reward_callback, observation_callback, info_callback) if cb is not None]
         fusable = isinstance(owner, HipScenario) and all(getattr(cb, "__self__", None) is owner for cb in cbs) \
             and observation_callback is not None and done_callback is None and not world.scripted_agents and owner.fused_step
+        self._fused_post_step = False
         if fusable and owner.dynamic:
-            # the fused kernel of a scenario with a post_step always applies it: usable exactly when the
-            # scenario's own (device) post_step is the post_step_callback
-            fusable = getattr(post_step_callback, "__self__", None) is owner and \
+            # the fused kernel of a scenario with a post_step applies it when the scenario's own (device) post_step
+            # is the post_step_callback, and leaves it out when there is no post_step_callback at all (what make_env
+            # builds, make_env.py:36-43); any other callback is called here, after an unfused step
+            own = getattr(post_step_callback, "__self__", None) is owner and \
                 getattr(post_step_callback, "__func__", None) is HipScenario.post_step
+            fusable = own or post_step_callback is None
+            self._fused_post_step = own
         elif fusable:
             fusable = post_step_callback is None
         self._scenario = owner if fusable else None
@@ -128,7 +132,7 @@ class MultiAgentEnv:
             info_n["r{}".format(i)] = r                                        # environment.py:100
         if self.shared_reward:
             reward_n = [np.sum(reward_n)] * self.n                             # environment.py:103-105
-        if self.post_step_callback is not None and not (fused and self._scenario.dynamic):
+        if self.post_step_callback is not None and not (fused and self._fused_post_step):
             self.post_step_callback(self.world, self.np_random)         # (the fused step of a dynamic scenario already applied it)
         return obs_n, reward_n, bool(any(done_n)), info_n                      # environment.py:110-115
 
@@ -170,7 +174,7 @@ class MultiAgentEnv:
     def _fused_step(self, action_n):
         """One mpe_step launch on the one-world batch: the state goes up and every result comes down in one copy each."""
         sc, world = self._scenario, self.world
-        ow = sc.one_world(world)
+        ow = sc.one_world(world, post_step=self._fused_post_step or not sc.dynamic)
         flat = []
         for i, agent in enumerate(self.agents):
             flat += self._action_ints(action_n[i], agent)
@@ -191,7 +195,7 @@ class MultiAgentEnv:
         if self.info_callback is not None:
             with sc.pinned():           # benchmark_data formats the step's own outputs, no second look at the world
                 info_list = [sc.benchmark_data(a, world) for a in self.agents]
-        if sc.dynamic:
+        if sc.dynamic and self._fused_post_step:
             # the kernel ran post_step after the callbacks: take over its pick-ups, hand-overs and respawns
             sc.absorb_from(world, ow, self.np_random)
         return obs_n, reward_n, info_list

@@ -19,8 +19,8 @@ _NP = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int
 
 
 class OneWorld:
-    def __init__(self, spec, device="cuda:0", info=False):
-        self.env = env = BatchedEnv(spec, 1, dtype=torch.float64, device=device, info=info)
+    def __init__(self, spec, device="cuda:0", info=False, post_step=True):
+        self.env = env = BatchedEnv(spec, 1, dtype=torch.float64, device=device, info=info, post_step=post_step)
         self.host = torch.zeros(env.arena.numel(), dtype=torch.uint8).pin_memory()
         raw = self.host.numpy()
         self.v = {}                     # numpy views of the host mirror, same names and shapes as the device tensors

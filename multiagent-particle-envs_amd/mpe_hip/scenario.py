@@ -54,21 +54,27 @@ class HipScenario(BaseScenario):
 
     def __init__(self):
         self._ow = None         # (signature, OneWorld)
+        self._ow_bare = None    # the same for the one-world batch whose step leaves post_step out
         self._cache = None      # (state key, obs [obs_total], rew [A], info_i, info_f)
         self._pinned = False
 
     # -- device plumbing ------------------------------------------------
-    def one_world(self, world):
-        """The one-world batch (with its pinned host mirror) matching the world's static properties."""
+    def one_world(self, world, post_step=True):
+        """The one-world batch (with its pinned host mirror) matching the world's static properties.  ``post_step=False``
+        (dynamic scenarios): the batch whose step ends after the callbacks, for an env built without a
+        post_step_callback."""
         from .oneworld import OneWorld
         sig = world._signature() + (tuple(bool(getattr(a, "adversary", False)) for a in world.agents),
                                     bool(getattr(world, "collaborative", False)))
-        if self._ow is None or self._ow[0] != sig:
+        slot = "_ow" if post_step else "_ow_bare"
+        have = getattr(self, slot)
+        if have is None or have[0] != sig:
             spec = spec_from_world(world, self.scenario_id, self.hip_name)
             want_info = self.has_info if self.fused_info is None else self.fused_info
-            self._ow = (sig, OneWorld(spec, device=world.device, info=want_info))
+            have = (sig, OneWorld(spec, device=world.device, info=want_info, post_step=post_step))
+            setattr(self, slot, have)
             self._cache = None
-        return self._ow[1]
+        return have[1]
 
     def fused_env(self, world):
         """The BatchedEnv behind one_world(world) (sizes, layout)."""

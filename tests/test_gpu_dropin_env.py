@@ -270,3 +270,33 @@ def test_batch_slice_as_world_objects(scenario):
     assert again is world and np.array_equal(np.array([e.state.p_pos for e in world.entities]), env.get_state()[0][b])
     with pytest.raises(IndexError):
         env.to_world(B)
+
+
+@pytest.mark.parametrize("name", ["collector", "simple_predator_prey"])
+def test_make_env_without_post_step_is_one_fused_launch_and_leaves_post_step_out(name):
+    """make_env passes no post_step_callback (make_env.py:36-43), so the reference's step never calls post_step
+    (environment.py:107-108): nothing is picked up, handed over or respawned.  That env steps as one fused launch whose
+    kernel leaves post_step out; it must equal the unfused path (World.step kernel + callbacks) that a do-nothing
+    post_step_callback forces, step for step."""
+    from make_env import make_env
+    from multiagent.environment import MultiAgentEnv
+    from mpe_hip import scenarios
+    fused = make_env(name)
+    assert fused._scenario is not None and not fused._fused_post_step
+    sc = scenarios.load(name + ".py").Scenario()
+    world = sc.make_world()
+    plain = MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, post_step_callback=lambda w, rng: None)
+    assert plain._scenario is None
+    for env in (fused, plain):
+        env.seed(11)
+    o1, o2 = fused.reset(), plain.reset()
+    assert all(np.array_equal(a, b) for a, b in zip(o1, o2))
+    landmarks0 = np.array([lm.state.p_pos for lm in fused.world.landmarks])
+    rng = np.random.RandomState(5)
+    for t in range(25):
+        act = [int(rng.randint(0, 5)) for _ in range(fused.n)]
+        o1, r1, d1, _ = fused.step(act)
+        o2, r2, d2, _ = plain.step(act)
+        assert all(_close(a, b) for a, b in zip(o1, o2)), t
+        assert _close(r1, r2) and d1 is False and d2 is False, t
+    assert np.array_equal(np.array([lm.state.p_pos for lm in fused.world.landmarks]), landmarks0)      # nothing was taken or respawned
