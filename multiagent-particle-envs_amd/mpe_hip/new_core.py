@@ -34,11 +34,9 @@ class World(_CoreWorld):
             self.min_dists = size[:, None] + size[None, :]
             np.fill_diagonal(self.min_dists, 0.0)
         pos = np.array([e.state.p_pos for e in ents], dtype=np.float64)
-        for ia in range(n):
-            for ib in range(ia + 1, n):
-                d = pos[ia] - pos[ib]
-                self.cached_dist_vect[ia, ib, :] = d
-                self.cached_dist_vect[ib, ia, :] = -d
+        # every pair at once: pos[a] - pos[b] for a != b (the reference fills [a, b] with the offset and [b, a] with its
+        # negation, and b - a == -(a - b) exactly in IEEE arithmetic); the diagonal stays zero
+        np.subtract(pos[:, None, :], pos[None, :, :], out=self.cached_dist_vect)
         self.cached_dist_mag = np.linalg.norm(self.cached_dist_vect, axis=2)
         self.cached_collisions = self.cached_dist_mag <= self.min_dists
 
