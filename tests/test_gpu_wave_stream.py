@@ -1,0 +1,117 @@
+"""Launches of several steps of float32 simple_spread worlds larger than 3/3 run on a kernel of their own (one wave
+steps the world, the other streams the observations as 16-byte vectors); a launch of one step runs on the
+workgroup-per-world kernel that both waves share.  The two must agree bit for bit: same operations in the same order
+(simple_spread.py:58-130, core.py:150-204)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+# A * (A + L + 1) even: the world's observation block is a whole number of 16-byte vectors (the streaming kernel);
+# the odd cases stay on the shared kernel and are here as the control
+SIZES = [(64, 64), (10, 7), (4, 9), (33, 32), (2, 1), (9, 5)]
+
+
+def _env(A, L, B, **kw):
+    import mpe_hip
+    spec = kw.pop("spec", None)
+    return mpe_hip.BatchedEnv(spec if spec is not None else "simple_spread", B, dtype=torch.float32, device="cuda:0",
+                              **({} if spec is not None else dict(n_agents=A, n_landmarks=L)), **kw)
+
+
+def _actions(T, B, A, seed):
+    gen = torch.Generator("cuda:0").manual_seed(seed)
+    return torch.randint(0, 5, (T, B, A), dtype=torch.int32, device="cuda:0", generator=gen)
+
+
+def _same_state(e1, e2):
+    assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.vel, e2.vel)
+
+
+@pytest.mark.parametrize("A,L", SIZES)
+@pytest.mark.parametrize("T", [2, 25, 71])
+def test_rollout_equals_repeated_step(A, L, T):
+    """71 steps: beyond two refills of the 32-step action buffer."""
+    B = 37 if A < 64 else 5
+    stepper, roller = _env(A, L, B, info=True), _env(A, L, B, info=True)
+    for e in (stepper, roller):
+        e.reset(seed=11, observe=False)
+    a = _actions(T, B, A, 1)
+    out = roller.rollout(a)
+    for t in range(T):
+        obs, rew, done, (ii, ff) = stepper.step(a[t])
+        assert torch.equal(obs, out["obs"][t]), (t, (obs != out["obs"][t]).nonzero()[:4])
+        assert torch.equal(rew, out["rew"][t]) and torch.equal(done, out["done"][t]), t
+        assert torch.equal(ii, out["info_i"][t]) and torch.equal(ff, out["info_f"][t]), t
+    _same_state(stepper, roller)
+
+
+@pytest.mark.parametrize("A,L", SIZES)
+def test_episode_launch_equals_reset_then_steps(A, L):
+    B, T = 130, 9          # 130 worlds: the done flags' 128-byte blocks, one whole and one ragged
+    stepper, epi = _env(A, L, B), _env(A, L, B)
+    a = _actions(T, B, A, 2)
+    out = epi.rollout(a, reset_seed=5, obs0=True)
+    first = stepper.reset(seed=5)
+    assert torch.equal(first, out["obs0"][0])
+    for t in range(T):
+        obs, rew, done, _ = stepper.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t]) and torch.equal(done, out["done"][t]), t
+    _same_state(stepper, epi)
+    assert not bool(out["done"].any())
+
+
+@pytest.mark.parametrize("A,L", [(64, 64), (10, 7), (9, 5)])
+def test_launch_of_several_episodes_equals_single_episode_launches(A, L):
+    B, K, P = 33, 3, 7
+    many, single = _env(A, L, B), _env(A, L, B)
+    a = _actions(K * P, B, A, 3)
+    out = many.rollout(a, reset_seed=21, episodes=K, obs0=True)
+    for k in range(K):
+        o = single.rollout(a[k * P:(k + 1) * P].contiguous(), reset_seed=21, obs0=True)
+        assert torch.equal(o["obs0"][0], out["obs0"][k]), k
+        for key in ("obs", "rew", "done"):
+            assert torch.equal(o[key], out[key][k * P:(k + 1) * P]), (k, key)
+    _same_state(many, single)
+    # the landmarks of the last episode are the ones left in the state
+    assert not torch.equal(out["obs0"][0], out["obs0"][K - 1])
+
+
+@pytest.mark.parametrize("A,L", [(64, 64), (4, 9)])
+def test_done_bound_and_speed_limit(A, L):
+    """A world's own done flag (any agent beyond the bound, environment.py:110-113,143-146) and Entity.max_speed
+    (core.py:199-203) in the streaming kernel."""
+    import mpe_hip
+    spec = mpe_hip.make_spec("simple_spread", n_agents=A, n_landmarks=L)
+    spec = dataclasses.replace(spec, max_speed=np.where(np.arange(A) % 2 == 0, 0.4, np.inf))
+    B, T = 40, 30
+    bound = 1.05 if A < 64 else 4.0        # 64 overlapping agents push one another out of the arena within a step or two
+    stepper, roller = _env(A, L, B, spec=spec, done_bound=bound), _env(A, L, B, spec=spec, done_bound=bound)
+    for e in (stepper, roller):
+        e.reset(seed=8, observe=False)
+    a = _actions(T, B, A, 4)
+    a[:, :, 0] = 2          # agent 0 runs to the right until it is out
+    out = roller.rollout(a)
+    for t in range(T):
+        obs, rew, done, _ = stepper.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t]) and torch.equal(done, out["done"][t]), t
+    _same_state(stepper, roller)
+    assert bool(out["done"].any()) and not bool(out["done"].all())
+    speed = stepper.vel.view(B, A, 2).norm(dim=-1)
+    assert float(speed[:, 0::2].max()) <= 0.4 * (1 + 1e-6)
+
+
+def test_out_of_range_actions_move_nothing():
+    """environment.py:176-195: an action index outside 1..4 leaves action.u at zero, also as a staged byte."""
+    A, L, B, T = 10, 7, 16, 4
+    good, odd = _env(A, L, B), _env(A, L, B)
+    for e in (good, odd):
+        e.reset(seed=1, observe=False)
+    a = _actions(T, B, A, 5)
+    b = a.clone()
+    b[a == 0] = torch.tensor([256, -1, 5, 1 << 20], dtype=torch.int32, device="cuda:0")[torch.arange(int((a == 0).sum()), device="cuda:0") % 4]
+    o1, o2 = good.rollout(a), odd.rollout(b)
+    assert torch.equal(o1["obs"], o2["obs"]) and torch.equal(o1["rew"], o2["rew"])
