@@ -14,6 +14,10 @@
 //
 // Epilogues: EPI_NONE  -- World.step only; forces and comm actions come in as arrays
 //            EPI_SPREAD -- int actions in, simple_spread observation / reward / benchmark_data out
+//
+// wave_kernel serves every launch of one step, the physics-only step, double worlds and worlds with noise.  Launches of
+// several steps of float simple_spread worlds run on wave_stream_kernel (further down), in which the two waves of a world
+// have different jobs: one steps, the other writes observations.
 #include <string.h>
 
 #include <mutex>
@@ -131,7 +135,7 @@ __device__ __forceinline__ int count_collisions(const V2<T>* S, const T* size_s,
     return c;
 }
 
-// Table indices of observation pair `pair` of a simple_spread world (simple_spread.py:110-130): the row of agent i is
+// Table indices of one coordinate pair of a simple_spread observation (simple_spread.py:110-130): the row of agent i is
 // its velocity, its position, the L landmarks and the other agents relative to it, RP = A + L + 1 pairs.  Low byte: index
 // of the minuend in the world's table of pairs (entity positions at 0.., velocities at MAX_E..); next byte: the
 // subtrahend (agent i, or ZERO for the row's own velocity and position).
@@ -141,18 +145,10 @@ __device__ __forceinline__ unsigned spread_row_entry(int i, int r, int A, int L,
     const int first = (r == 0) ? MAX_E + i : (r == 1 ? i : src);
     return (unsigned)first | ((unsigned)(r >= 2 ? i : zero_slot) << 8);
 }
-__device__ __forceinline__ unsigned spread_pair_entry(int pair, int A, int L, int zero_slot) {
-    const int RP = A + L + 1;
-    const int i = (int)(((float)pair + 0.5f) / (float)RP), r = pair - i * RP;       // pair < 2^13: exact
-    return spread_row_entry(i, r, A, L, zero_slot);
-}
 
 // NOISE: agents with u_noise (its own instantiation: the generator is an out-of-line call).
-// QUADS: the observation block leaves as 16-byte vectors of two coordinate pairs (float worlds whose block is a whole
-// number of them, 16-byte aligned arrays), each lane keeping the packed table indices of its vectors in registers.
-constexpr int MAX_QUADS_PER_LANE = (MPE_MAX_AGENTS * (MPE_MAX_AGENTS + MPE_MAX_LANDMARKS + 1) / 2 + NT - 1) / NT;
-template <typename T, int EPI, int MODE, bool CLAMP, bool NOISE = false, bool QUADS = false>
-__global__ __launch_bounds__(NT, (QUADS || (MPE_WAVE_F64_WAVES == 4 && sizeof(T) == 8 && EPI == EPI_SPREAD)) ? 4 : 1) void wave_kernel(const WaveParams<T> p, const ResetArgs rs, const AutoArgs au, const int* __restrict__ actions,
+template <typename T, int EPI, int MODE, bool CLAMP, bool NOISE = false>
+__global__ __launch_bounds__(NT, (MPE_WAVE_F64_WAVES == 4 && sizeof(T) == 8 && EPI == EPI_SPREAD) ? 4 : 1) void wave_kernel(const WaveParams<T> p, const ResetArgs rs, const AutoArgs au, const int* __restrict__ actions,
                                                   const T* __restrict__ u_g, const T* __restrict__ c_g,
                                                   T* __restrict__ pos_g, T* __restrict__ vel_g, T* __restrict__ comm_g,
                                                   T* __restrict__ obs_g, T* __restrict__ rew_g, uint8_t* __restrict__ done_g,
@@ -160,8 +156,7 @@ __global__ __launch_bounds__(NT, (QUADS || (MPE_WAVE_F64_WAVES == 4 && sizeof(T)
                                                   int n_steps) {
     // entity positions (agents first) and agent velocities in one array, so that the observation
     // loop can fetch either with one computed index
-    __shared__ V2<T> PV[MAX_E + MPE_MAX_AGENTS + 1];       // + one pair of zeros (the subtrahend of a row's own velocity and position)
-    constexpr int ZERO_SLOT = MAX_E + MPE_MAX_AGENTS;
+    __shared__ V2<T> PV[MAX_E + MPE_MAX_AGENTS];
     V2<T>* const P = PV;
     V2<T>* const Vel = PV + MAX_E;
     __shared__ T size_s[MAX_E];
@@ -200,7 +195,6 @@ __global__ __launch_bounds__(NT, (QUADS || (MPE_WAVE_F64_WAVES == 4 && sizeof(T)
     };
     // ---- stage the world ----
     for (int e = lane; e < E; e += NT) size_s[e] = (T)tb->size[e];
-    if (lane == 0) { PV[ZERO_SLOT].x = T(0); PV[ZERO_SLOT].y = T(0); }
     if (rs.enabled) {       // fused Scenario.reset_world
         draw_world(rs);
     } else {
@@ -264,44 +258,7 @@ __global__ __launch_bounds__(NT, (QUADS || (MPE_WAVE_F64_WAVES == 4 && sizeof(T)
     // reads of several iterations are in flight together, and (i, r) advance incrementally.
     // (Plain stores also in a launch of one step: as non-temporal 8-byte stores, see put<>, the block took 37.4 us
     // instead of 35.4 at 64/64 x 2 048 worlds.)
-    // QUADS: vector k of a lane covers pairs 2q and 2q + 1, q = k * NT + lane; its four PV indices (minuend and subtrahend
-    // of each pair, a byte each) are worked out once per launch.  16-byte stores halve the store instructions of the
-    // block and leave two subtractions and four LDS reads per vector.
-    unsigned quad_tab[QUADS ? MAX_QUADS_PER_LANE : 1];
-    if constexpr (QUADS) {
-        const int RP = OD / 2, total = A * RP;
-        auto entry = [&](int pair) -> unsigned { return spread_pair_entry(pair, A, L, ZERO_SLOT); };
-#pragma unroll
-        for (int k = 0; k < MAX_QUADS_PER_LANE; ++k) {
-            const int q = k * NT + lane;
-            quad_tab[k] = (2 * q < total) ? (entry(2 * q) | (entry(2 * q + 1) << 16)) : 0u;
-        }
-    }
     auto emit_obs = [&](T* world_block) {
-        if constexpr (QUADS) {
-            typedef T T4 __attribute__((ext_vector_type(4)));
-            const int n_quads = (A * (OD / 2)) / 2;
-            T4* dst = reinterpret_cast<T4*>(world_block) + lane;
-#pragma unroll
-            for (int k = 0; k < MAX_QUADS_PER_LANE; ++k) {
-                if (k * NT >= n_quads) break;
-                if (k * NT + lane < n_quads) {
-                    unsigned e = quad_tab[k];
-                    asm volatile("" : "+v"(e));     // unpacked here, every step: hoisted out of the step loop the 132 addresses are 132 registers
-                    const V2<T> a0 = PV[e & 255u], b0 = PV[(e >> 8) & 255u], a1 = PV[(e >> 16) & 255u], b1 = PV[e >> 24];
-                    T4 w;
-                    w.x = spread_round<T>(a0.x - b0.x);
-                    w.y = spread_round<T>(a0.y - b0.y);
-                    w.z = spread_round<T>(a1.x - b1.x);
-                    w.w = spread_round<T>(a1.y - b1.y);
-                    dst[k * NT] = w;
-                }
-                // four vectors' LDS reads in flight at a time: the scheduler would otherwise hoist every read of the
-                // unrolled loop (200 registers)
-                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-            return;
-        }
         const int RP = OD / 2, total = A * RP;
         typedef T T2 __attribute__((ext_vector_type(2)));
         // the world's block starts at a multiple of A*OD values and OD is even: pair q is 2*sizeof(T)-aligned
@@ -831,17 +788,13 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
     dim3 grid((unsigned)B), block(NT);
     if constexpr (EPI == EPI_SPREAD && MODE == WMODE_STEP && sizeof(T) == 4) {
         // a world's block is A * (A + L + 1) coordinate pairs: 16-byte vectors when that is even and the arrays are aligned
-#ifdef MPE_WAVE_NO_QUADS     // diagnostic build: 8-byte stores throughout
-        const bool aligned = false;
-#else
         const bool aligned = (((uintptr_t)a.obs | (uintptr_t)a.obs0) & 15u) == 0;
-#endif
         const bool quads = aligned && ((s.A * (s.A + s.L + 1)) & 1) == 0;
-#ifndef MPE_WAVE_NO_STREAM
+#ifndef MPE_WAVE_NO_STREAM   // (defined in diagnostic builds: every launch on wave_kernel)
         // launches of several steps: one wave steps, the other streams (wave_stream_kernel)
         if (quads && !a.noise.enabled && a.au.step_count == nullptr && a.n_steps > 1) {
             // A launch that streams large blocks ends with the odd XCDs, which write 15-20 % more slowly than the even ones
-            // while all eight stream (measured per XCD with timestamps; the same on every box): give an even XCD's CUs
+            // while all eight stream (per-XCD timestamps, on every box measured): give an even XCD's CUs
             // m + d worlds each and an odd XCD's m - d, d / m about an eighth.  Whole worlds per CU on both sides matter
             // (2 048 worlds of 64 + 64: 8 : 8 per CU 0.698 ms, 8.5 : 7.5 0.689, 9 : 7 0.664, 9.25 : 6.75 0.696; 1 536 worlds
             // 0.559 -> 0.513 ms at 7 : 5; 4 096 worlds 1.402 -> 1.323 ms at 18 : 14); below six worlds per CU a split costs
@@ -862,11 +815,6 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
             return hipGetLastError();
         }
 #endif
-        if (!a.noise.enabled && !s.any_speed_limit() && quads) {
-            hipLaunchKernelGGL((wave_kernel<T, EPI, MODE, false, false, true>), grid, block, 0, st, p, a.reset, a.au, a.actions, (const T*)u, (const T*)c,
-                               (T*)a.pos, (T*)a.vel, (T*)a.comm, (T*)a.obs, (T*)a.rew, a.done, a.info_i, (T*)a.info_f, (T*)a.obs0, a.noise, a.n_steps);
-            return hipGetLastError();
-        }
     }
     if constexpr (EPI == EPI_SPREAD && MODE == WMODE_STEP) {
         if (a.noise.enabled) {
