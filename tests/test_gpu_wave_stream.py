@@ -115,3 +115,43 @@ def test_out_of_range_actions_move_nothing():
     b[a == 0] = torch.tensor([256, -1, 5, 1 << 20], dtype=torch.int32, device="cuda:0")[torch.arange(int((a == 0).sum()), device="cuda:0") % 4]
     o1, o2 = good.rollout(a), odd.rollout(b)
     assert torch.equal(o1["obs"], o2["obs"]) and torch.equal(o1["rew"], o2["rew"])
+
+
+@pytest.mark.parametrize("B", [1300, 3100])
+def test_worlds_split_unevenly_over_the_xcds(B):
+    """From six worlds per CU on, a launch of 64/64 worlds deals more worlds to the even XCDs than to the odd ones
+    (workgroup index -> world is then a permutation with idle workgroups at the end of every XCD's share): every
+    world must still be stepped exactly once, also when the batch does not fill the last shares."""
+    A = L = 64
+    T = 3
+    stepper, roller = _env(A, L, B), _env(A, L, B)
+    a = _actions(T, B, A, 6)
+    out = roller.rollout(a, reset_seed=4, obs0=True)
+    assert torch.equal(stepper.reset(seed=4), out["obs0"][0])
+    for t in range(T):
+        obs, rew, done, _ = stepper.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t]) and torch.equal(done, out["done"][t]), t
+    _same_state(stepper, roller)
+
+
+def test_stream_launch_under_graph_capture():
+    """The launch is one kernel on the caller's stream: it can be captured and replayed."""
+    A, L, B, T = 10, 7, 64, 6
+    env, ref = _env(A, L, B), _env(A, L, B)
+    a = _actions(T, B, A, 7)
+    want = ref.rollout(a, reset_seed=9, obs0=True)
+    out = env.rollout(a, reset_seed=9, obs0=True)          # allocates the outputs
+    for v in out.values():
+        if v is not None:
+            v.zero_()
+    env._episode = 0
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            env.rollout(a, out=out, reset_seed=9, obs0=True)
+    g.replay()
+    torch.cuda.synchronize()
+    for key in ("obs0", "obs", "rew", "done"):
+        assert torch.equal(out[key], want[key]), key
