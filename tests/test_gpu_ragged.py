@@ -79,3 +79,30 @@ def test_long_and_short_rollouts_equal_stepping(scenario, T):
                     assert (x == y).all(), (scenario, dtype, "history")
             else:
                 assert torch.equal(e1.comm, e2.comm), (scenario, dtype, "comm")
+
+
+@pytest.mark.parametrize("scenario,B", [("simple_spread", 8192 * 64 + 3 * 64 + 5), ("simple_tag", 8192 * 64 + 64)])
+def test_launch_of_many_rounds_deals_tiles_unevenly_to_the_xcds(scenario, B):
+    """From 8 192 tiles on, an episode launch gives the even XCDs 9 tiles for every 7 of the odd ones (workgroup index ->
+    tile is then a permutation, with idle workgroups at the end of every share): every env must be stepped exactly once,
+    the done flags' shared 128-byte lines included, with an odd number of tiles and a ragged tail."""
+    import mpe_hip
+    T = 3
+    e1 = mpe_hip.BatchedEnv(scenario, B, dtype=torch.float32, device="cuda:0", info=False)
+    e2 = mpe_hip.BatchedEnv(scenario, B, dtype=torch.float32, device="cuda:0", info=False)
+    a = torch.randint(0, 5, (T, B, e1.layout.n_act), dtype=torch.int32, device="cuda:0", generator=torch.Generator("cuda:0").manual_seed(B))
+    obs0 = e1.reset(seed=17)
+    out = e2.rollout(a, reset_seed=17, obs0=True)
+    out["done"].fill_(7)
+    out = e2.rollout(a, out=out)      # a second launch from the state the first one left, into flags that are not zero
+    assert not bool(out["done"].any())
+    e3 = mpe_hip.BatchedEnv(scenario, B, dtype=torch.float32, device="cuda:0", info=False)
+    first = e3.rollout(a, reset_seed=17, obs0=True)
+    assert torch.equal(first["obs0"].reshape(obs0.shape), obs0)
+    for t in range(T):
+        obs, rew, done, _ = e1.step(a[t])
+        assert torch.equal(obs, first["obs"][t]) and torch.equal(rew, first["rew"][t]) and torch.equal(done, first["done"][t]), t
+    for t in range(T):
+        obs, rew, done, _ = e1.step(a[t])
+        assert torch.equal(obs, out["obs"][t]) and torch.equal(rew, out["rew"][t]), t
+    assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.vel, e2.vel)
