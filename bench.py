@@ -649,7 +649,8 @@ def main():
                          "traffic": stored_traffic("%s_%s_B%d_%s" % (args.scenario, args.dtype, B, args.mode)),
                          # VALU use of the same kernel, from the same kind of stored counter pass (null otherwise)
                          "valu": stored_valu("%s_%s_B%d_%s" % (args.scenario, args.dtype, B, args.mode)),
-                         "kernel": "%s<%s, %s, %s>" % ("consensus_kernel" if args.scenario == "consensus" else ("wave_kernel" if lo.state_env_major else "small_kernel"),
+                         "kernel": "%s<%s, %s, %s>" % ("consensus_kernel" if args.scenario == "consensus" else (("wave_stream_kernel" if s == 4 and args.mode == "rollout" and (lo.n_agents * (lo.n_agents + lo.n_landmarks + 1)) % 2 == 0
+                                                         else "wave_kernel") if lo.state_env_major else "small_kernel"),
                                                        "float" if s == 4 else "double", args.scenario, "rollout" if args.mode == "rollout" else "step"),
                          "bytes_per_env_step": bytes_env_step, "bytes_per_launch": bytes_launch,
                          "launch_ms": kern_ms, "launch_ms_source": kern_src, "event_pairs": n_pairs, "launches": launches},

@@ -1,5 +1,5 @@
 #!/bin/bash
-# On the GPU box: tools/collect_profiles.py for the seven profiled configs, one after the other, into
+# On the GPU box: tools/collect_profiles.py for the eight profiled configs, one after the other, into
 # gpurun_out/<tag>/prof_<name>/.  tools/merge_profiles.py then copies the summaries into profiles/.
 # usage: bash tools/collect_all_profiles.sh r02
 tag=${1:-r02}
@@ -10,6 +10,7 @@ run spread3 &&
 run tag --scenario simple_tag --envs 131072 &&
 run wcomm --scenario simple_world_comm --envs 262144 &&
 run spread64 --envs 2048 -- --agents 64 --landmarks 64 --no-step-mode &&   # (single steps run the same kernel: they would mix into its average)
+run spread64_f64 --envs 2048 --dtype f64 -- --agents 64 --landmarks 64 --no-step-mode &&
 run consensus --scenario consensus --envs 65536 &&
 run collector --scenario collector --envs 65536 &&
 run pp --scenario simple_predator_prey --envs 131072

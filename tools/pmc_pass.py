@@ -25,7 +25,7 @@ cmd = ["rocprofv3", "--pmc"] + names + ["--output-format", "csv", "-d", out, "--
 rc = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200).returncode
 if rc != 0:
     sys.exit("rocprofv3 failed with %d" % rc)
-mode_re = re.compile(r"(?:>|Cfg), (?:true|false), 1, (?:true|false), (?:true|false), \d+(?:, (?:true|false))?>\(|consensus_kernel<\w+, 1(?:, (?:true|false))?>|wave_kernel<\w+, 1, 0")
+mode_re = re.compile(r"(?:>|Cfg), (?:true|false), 1, (?:true|false), (?:true|false), \d+(?:, (?:true|false))?>\(|consensus_kernel<\w+, 1(?:, (?:true|false))?>|wave_kernel<\w+, 1, 0|wave_stream_kernel<")
 acc = {n: [] for n in names}
 for fn in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(fn)):
