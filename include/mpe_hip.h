@@ -193,7 +193,12 @@ typedef struct MpeLayout {
 typedef struct MpeHandle MpeHandle;
 
 /* Scenario.make_world() + MultiAgentEnv.__init__ (make_env.py:36-43, environment.py:15-69)
- * for n_envs worlds of one scenario on HIP device `device`. */
+ * for n_envs worlds of one scenario on HIP device `device`.  The handle owns a few bytes of device
+ * memory (one word that the large multi-step launches use to deal their workgroups unevenly to the
+ * GPU's XCDs, and the per-entity table of the scaled simple_spread / physics-only worlds), allocated
+ * here and freed by mpe_destroy; the stepping entry points allocate nothing.  Launches on one handle
+ * must be ordered (one stream, or events between streams): they share that word as they share the
+ * caller's state arrays.  MPE_XCD_SPLIT=0 in the environment switches the uneven deal off. */
 int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHandle** out);
 int mpe_destroy(MpeHandle* h);
 int mpe_layout(const MpeHandle* h, MpeLayout* out);

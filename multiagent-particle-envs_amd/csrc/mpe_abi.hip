@@ -18,6 +18,7 @@ struct MpeHandle {
     int device;
     bool use_wave;          // wave-per-world kernels, env-major state
     DevTable* table;        // device copy of the per-entity table (wave kernels only)
+    int* xcd_phase;         // device word of the uneven deal over the XCDs (XcdDeal): the XCD of a launch's workgroup 0
     // Agent.u_noise / c_noise draws: generator key, steps run since mpe_set_noise, and the draw array of the next launch
     unsigned long long noise_seed, noise_step;
     const void* noise_draws;
@@ -347,14 +348,26 @@ int mpe_create(const MpeSpec* spec, int64_t n_envs, int dtype, int device, MpeHa
             return hip_fail(nullptr, e, "mpe_create: device table");
         }
     }
+    {
+        DeviceScope scope(device);
+        hipError_t e;
+        if ((e = scope.status) != hipSuccess || (e = hipMalloc((void**)&h->xcd_phase, sizeof(int))) != hipSuccess ||
+            (e = hipMemset(h->xcd_phase, 0, sizeof(int))) != hipSuccess) {
+            if (h->xcd_phase) (void)hipFree(h->xcd_phase);
+            if (h->table) (void)hipFree(h->table);
+            delete h;
+            return hip_fail(nullptr, e, "mpe_create: phase word");
+        }
+    }
     *out = h;
     return MPE_OK;
 }
 
 int mpe_destroy(MpeHandle* h) {
-    if (h && h->table) {
+    if (h && (h->table || h->xcd_phase)) {
         DeviceScope scope(h->device);
-        (void)hipFree(h->table);
+        if (h->table) (void)hipFree(h->table);
+        if (h->xcd_phase) (void)hipFree(h->xcd_phase);
     }
     delete h;
     return MPE_OK;
@@ -374,6 +387,7 @@ static int run(MpeHandle* h, int mode, const StepArgs& args, mpe_stream_t stream
     a.env_base = a.reset.env_base = a.au.env_base = h->env_base;
     a.done_bound = h->done_bound;
     a.skip_post_step = h->skip_post_step;
+    a.xcd_phase = xcd_split_enabled() ? h->xcd_phase : nullptr;
     if (mode != 2 && h->spec.any_noise()) {
         a.noise = NoiseArgs{1, h->spec.noise_stride(), h->noise_draws, h->noise_seed, h->noise_step, h->env_base};
         if (((uintptr_t)h->noise_draws & (h->dtype == MPE_F64 ? 7u : 3u)) != 0) return fail(h, MPE_ERR_INVALID, "%s: misaligned noise draws", who);

@@ -31,7 +31,7 @@ struct ConsensusParams {
     int ghost;
     long long n_envs;
     T done_bound;       // > 0: a world is done when an agent leaves [-done_bound, done_bound]^2 (mpe_set_done_bound)
-    int per_xcd[2];     // > 0: workgroups' worth of worlds of an even / an odd XCD (0: equal shares)
+    XcdDeal deal;       // groups of 32 worlds dealt unevenly to even and odd XCDs (phase == nullptr: equal shares)
 };
 
 // neighbors(), consensus.py:79-83: the ring neighbours of agent i in ascending order
@@ -84,10 +84,10 @@ __global__ __launch_bounds__(NT) void consensus_kernel(const ConsensusParams<T> 
     // rows -- only: any placement gives the same result).
     const unsigned G = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
     unsigned group = xcd * (G >> 3) + (xcd < (G & 7u) ? xcd : (G & 7u)) + idx;
-    if (p.per_xcd[0] > 0) {
-        if (idx >= (unsigned)p.per_xcd[xcd & 1u]) return;
-        group = (xcd >> 1) * (unsigned)(p.per_xcd[0] + p.per_xcd[1]) + (xcd & 1u) * (unsigned)p.per_xcd[0] + idx;
-        if ((long long)group * WPG >= B) return;
+    if (p.deal.phase != nullptr) {
+        const long long unit = xcd_unit(p.deal, blockIdx.x);
+        if (unit < 0) return;
+        group = (unsigned)unit;
     }
     const long long env0 = (long long)group * WPG;
     const long long left = B - env0;
@@ -487,16 +487,16 @@ hipError_t launch_consensus_t(const HostSpec& s, long long B, int mode, const St
     auto p = make_consensus_params<T>(s, B);
     p.done_bound = (T)a.done_bound;
     dim3 grid((unsigned)((B + WPG - 1) / WPG)), block(NT);
-    p.per_xcd[0] = p.per_xcd[1] = 0;
-    // Launches of several steps run as four or more rounds of resident workgroups and end on the odd XCDs, which write
-    // 15-20 % more slowly while all eight stream: deal the workgroups 9 : 7 between even and odd XCDs (65 536 worlds
-    // 0.670 -> 0.652 ms, 262 144 worlds 2.599 -> 2.537 ms; 8.5 : 7.5 gains nothing).
+    p.deal = XcdDeal{nullptr, {0, 0}, (long long)grid.x};
+    // Launches of several steps run as four or more rounds of resident workgroups and end on the odd XCDs (XcdDeal,
+    // mpe_launch.hpp): the groups of 32 worlds are dealt 9 : 7 between even and odd XCDs (65 536 worlds 0.670 -> 0.652 ms,
+    // 262 144 worlds 2.599 -> 2.537 ms; 8.5 : 7.5 gains nothing).
     if (mode == 1 && grid.x >= 2048u) {
-        const long long G = grid.x, per = (G + 7) / 8, even = (per * 9 + 7) / 8, left = G - 4 * even;
-        const long long odd = left > 0 ? (left + 3) / 4 : 0;
-        if (odd > 0 && 8 * even < 0x7fffffffLL) {
-            p.per_xcd[0] = (int)even; p.per_xcd[1] = (int)odd;
-            grid = dim3((unsigned)(8 * even));
+        p.deal = make_xcd_deal(a.xcd_phase, (long long)grid.x, 1);
+        if (p.deal.phase != nullptr) {
+            grid = dim3((unsigned)(8 * p.deal.share[0]));
+            const hipError_t e = launch_xcd_phase(a.xcd_phase, st);
+            if (e != hipSuccess) return e;
         }
     }
     T *pos = (T*)a.pos, *vel = (T*)a.vel, *hist = (T*)a.comm, *obs = (T*)a.obs, *rew = (T*)a.rew;

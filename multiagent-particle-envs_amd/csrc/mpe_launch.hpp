@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mpe_hip.h"
 
@@ -105,6 +106,7 @@ struct StepArgs {
     unsigned long long env_base;      // global index of the batch's first env (mpe_set_env_base): keys every on-device draw
     double done_bound;                // > 0: done_callback "an agent is outside [-bound, bound]^2" (mpe_set_done_bound); 0: none
     int skip_post_step;               // 1: a scenario's post_step is not applied by the stepping launches (mpe_set_post_step(h, 0))
+    int* xcd_phase;           // the handle's phase word for an uneven deal over the XCDs (XcdDeal), or nullptr
 };
 
 // simple_spread.py:53 draws landmarks from U(-1,1); simple_tag.py:53 and simple_world_comm.py:106-112
@@ -146,4 +148,43 @@ hipError_t launch_world_step_static(const HostSpec& s, const DevTable& table, in
                                     void* pos, void* vel, void* comm, int n_speak_rows, hipStream_t st);
 // resolves the static array's address on `device` (which must be current) ahead of the first mpe_world_step_static
 hipError_t prepare_static_scratch(int device);
+
+// ---- an uneven deal of a launch's units (worlds, tiles, workgroups' worth of worlds) to the eight XCDs ----
+//
+// While all eight XCDs stream rows, the odd ones write 15-20 % more slowly than the even ones (per-XCD timestamps and
+// the L2's DRAM write-credit stalls), so a launch that is bound by its stores from beginning to end finishes on the odd
+// XCDs alone.  Giving an even XCD `share[0]` units and an odd one `share[1]` lets them finish together.
+// The dispatcher deals a launch's workgroups to the XCDs round-robin, but the XCD of workgroup 0 varies with the queue's
+// history (0 in a fresh process, something else after other streams or graphs have run).  So a one-workgroup launch on
+// the same stream, right before the kernel, stores the XCC_ID it runs on -- the phase s -- in the handle's `phase` word,
+// and the kernel takes workgroup i for slot (i + s) / 8 of XCD (i + s) % 8 (less one for the XCDs before s, whose first row
+// is missing).  For any value of s that is a bijection between workgroups and (XCD, slot) pairs, so every unit is
+// taken exactly once whatever the hardware does; only the speed depends on the guess being right.  (Counters per XCD
+// drawn with atomics would not need the guess, but 2 304 device-scope atomics on one line cost the launch 140 us.)
+struct XcdDeal {
+    const int* phase;       // nullptr: workgroup i takes unit i
+    int share[2];           // units of an even / an odd XCD
+    long long units;        // units of the launch; 4 * (share[0] + share[1]) >= units
+};
+
+// share[0] : share[1] about 9 : 7, both multiples of `quantum` (whole worlds per CU matter where a launch is one round of
+// resident workgroups: quantum 32 there); the grid to launch is 8 * share[0] workgroups.
+inline XcdDeal make_xcd_deal(const int* phase, long long units, long long quantum) {
+    XcdDeal d{nullptr, {0, 0}, units};
+    if (phase == nullptr || units <= 0) return d;
+    const long long per = (units + 7) / 8;
+    const long long even = ((per * 9 + 7) / 8 + quantum - 1) / quantum * quantum, left = units - 4 * even;
+    const long long odd = left > 0 ? ((left + 3) / 4 + quantum - 1) / quantum * quantum : 0;
+    if (odd <= 0 || 8 * even >= 0x7fffffffLL) return d;
+    d.phase = phase; d.share[0] = (int)even; d.share[1] = (int)odd;
+    return d;
+}
+
+// Switched off for the process by MPE_XCD_SPLIT=0 in the environment, read once.
+inline bool xcd_split_enabled() {
+    static const bool on = [] { const char* e = getenv("MPE_XCD_SPLIT"); return !(e != nullptr && e[0] == '0'); }();
+    return on;
+}
+// the one-workgroup launch that stores the phase (mpe_reset.hip)
+hipError_t launch_xcd_phase(int* phase, hipStream_t st);
 }  // namespace mpe

@@ -246,6 +246,20 @@ template <typename T> __device__ __forceinline__ V2<T> decode_move(int a, T sens
     return u;
 }
 
+// ---- XcdDeal, device side (see mpe_launch.hpp) ----
+__device__ __forceinline__ unsigned hw_xcc_id() {
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20), bits 2:0: simm16 = (size - 1) << 11 | offset << 6 | id
+    return __builtin_amdgcn_s_getreg((2 << 11) | (0 << 6) | 20) & 7u;
+}
+// The unit workgroup `wg` takes, or -1 (uniform over the workgroup: every thread may call it).
+__device__ __forceinline__ long long xcd_unit(const XcdDeal& d, unsigned wg) {
+    const unsigned s = (unsigned)*d.phase & 7u;
+    const unsigned j = wg + s, x = j & 7u, slot = (j >> 3) - (x < s ? 1u : 0u);
+    if (slot >= (unsigned)d.share[x & 1u]) return -1;
+    const long long unit = (long long)(x >> 1) * (d.share[0] + d.share[1]) + (x & 1u) * d.share[0] + slot;
+    return unit < d.units ? unit : -1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Counter-based uniform generator for on-device reset: Philox-4x32-10.
 // ---------------------------------------------------------------------------------------------

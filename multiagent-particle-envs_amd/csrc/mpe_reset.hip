@@ -60,4 +60,16 @@ hipError_t launch_reset(const HostSpec& s, long long B, int dtype, int comm_rows
     return hipGetLastError();
 }
 
+// The phase of an uneven deal over the XCDs (XcdDeal, mpe_launch.hpp): one workgroup stores the XCD it runs on, i.e. the
+// XCD that workgroup 0 of the next launch on this stream will be dealt to.
+__global__ __launch_bounds__(64) void xcd_phase_kernel(int* __restrict__ phase) {
+    const unsigned id = hw_xcc_id();
+    if (threadIdx.x == 0) *phase = (int)id;
+}
+
+hipError_t launch_xcd_phase(int* phase, hipStream_t st) {
+    hipLaunchKernelGGL(xcd_phase_kernel, dim3(1), dim3(64), 0, st, phase);
+    return hipGetLastError();
+}
+
 }  // namespace mpe

@@ -27,7 +27,7 @@ struct SmallParams {
     unsigned long long env_base;                // global index of the batch's first env (counter of the respawn draws)
     T done_bound;                               // > 0: an env is done when an agent leaves [-done_bound, done_bound]^2; 0: never
     int skip_post_step;                         // scenarios with a post_step: 1 = the step ends after the callbacks (post_step_callback=None)
-    int per_xcd[2];      // > 0: tiles of an even / an odd XCD (0: workgroup i is tile i)
+    XcdDeal deal;        // tiles dealt unevenly to even and odd XCDs (phase == nullptr: workgroup i is tile i)
     // read by scenarios on the new_core physics with walls only
     T force_scale[A];                           // mass (* accel): new_core.py:214
     T wall_axis_pos[SMALL_MAX_WALLS], wall_end0[SMALL_MAX_WALLS], wall_end1[SMALL_MAX_WALLS], wall_width[SMALL_MAX_WALLS];

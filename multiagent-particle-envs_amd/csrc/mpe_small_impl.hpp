@@ -197,11 +197,10 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
     const int lane = threadIdx.x;
     const long long B = p.n_envs;
     unsigned tile = blockIdx.x;
-    if (p.per_xcd[0] > 0) {     // tiles dealt unevenly to even and odd XCDs (launch_range)
-        const unsigned x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        if (slot >= (unsigned)p.per_xcd[x & 1u]) return;
-        tile = (x >> 1) * (unsigned)(p.per_xcd[0] + p.per_xcd[1]) + (x & 1u) * (unsigned)p.per_xcd[0] + slot;
-        if ((long long)tile * EPW >= env_end - env_begin) return;
+    if (p.deal.phase != nullptr) {     // tiles dealt unevenly to even and odd XCDs (launch_range)
+        const long long unit = xcd_unit(p.deal, blockIdx.x);
+        if (unit < 0) return;
+        tile = (unsigned)unit;
     }
     const long long env0 = env_begin + (long long)tile * EPW;
     const long long left = env_end - env0;
@@ -762,7 +761,7 @@ static SmallParams<T, Cfg::E, Cfg::A> make_params(const HostSpec& s, long long n
     p.env_base = env_base;
     p.done_bound = T(0);
     p.skip_post_step = 0;
-    p.per_xcd[0] = p.per_xcd[1] = 0;
+    p.deal = XcdDeal{nullptr, {0, 0}, 0};
     for (int e = 0; e < Cfg::E; ++e) p.size_d[e] = s.size[e];
     for (int i = 0; i < Cfg::A; ++i) { p.u_noise[i] = (T)s.u_noise[i]; p.c_noise[i] = (T)s.c_noise[i]; }
     for (int i = 0; i < Cfg::A; ++i) { p.force_scale[i] = (T)s.force_scale[i]; p.ghost[i] = s.ghost[i]; }
@@ -780,20 +779,17 @@ static void launch_range(const SmallParams<T, Cfg::E, Cfg::A>& p, long long env_
     if (env_end <= env_begin) return;
     dim3 grid((unsigned)((env_end - env_begin + EPW - 1) / EPW)), block(64);
     SmallParams<T, Cfg::E, Cfg::A> q = p;
-    // Workgroups go to the eight XCDs round-robin by index, and while all eight stream rows the odd XCDs write 15-20 %
-    // more slowly than the even ones.  A launch of many rounds of waves therefore ends on the odd XCDs alone; dealing
-    // the tiles 9 : 7 (workgroup i is slot i / 8 of XCD i % 8, slots beyond the XCD's share end at once) lets them end
-    // together: simple_spread 1.050 -> 1.008 ms at 1 048 576 worlds, 4.235 -> 4.078 ms at 4 194 304, simple_tag 1.567 ->
-    // 1.458 ms at 1 048 576, float64 2.011 -> 1.932 ms.  Not below four rounds (the BASELINE sizes lose: 65 536 worlds
-    // 59.8 -> 65.2 us, simple_tag at 131 072 worlds 184 -> 196 us; those launches half-fit the Infinity Cache and are
-    // not bound the same way) and not for the cooperative-pass scenarios (collector at 262 144 worlds 3.6 -> 4.2 ms).
+    // A launch of many rounds of waves ends on the odd XCDs alone (XcdDeal, mpe_launch.hpp); dealing the tiles 9 : 7 lets
+    // the XCDs end together: simple_spread 1.050 -> 1.008 ms at 1 048 576 worlds, 4.235 -> 4.078 ms at 4 194 304,
+    // simple_tag 1.567 -> 1.458 ms at 1 048 576, float64 2.011 -> 1.932 ms.  Not below four rounds (the BASELINE sizes
+    // lose: 65 536 worlds 59.8 -> 65.2 us, simple_tag at 131 072 worlds 184 -> 196 us; those launches half-fit the
+    // Infinity Cache and are not bound the same way) and not for the cooperative-pass scenarios (collector at 262 144
+    // worlds 3.6 -> 4.2 ms).  Even shares: the done flags' pairs of tiles stay on one side.
     if (MODE == MODE_ROLLOUT && FULL && !Cfg::OBS_COOP && grid.x >= 8192u) {
-        const long long tiles = grid.x, per = (tiles + 7) / 8;
-        const long long even = ((per * 9 + 7) / 8 + 1) & ~1LL, left = tiles - 4 * even;      // even counts: the done flags' pairs
-        const long long odd = left > 0 ? ((left + 3) / 4 + 1) & ~1LL : 0;
-        if (odd > 0 && 8 * even < 0x7fffffffLL) {
-            q.per_xcd[0] = (int)even; q.per_xcd[1] = (int)odd;
-            grid = dim3((unsigned)(8 * even));
+        q.deal = make_xcd_deal(a.xcd_phase, (long long)grid.x, 2);
+        if (q.deal.phase != nullptr) {
+            grid = dim3((unsigned)(8 * q.deal.share[0]));
+            if (launch_xcd_phase(a.xcd_phase, st) != hipSuccess) return;        // (hipGetLastError reports it to the caller)
         }
     }
     hipLaunchKernelGGL((small_kernel<T, Cfg, CLAMP, MODE, FULL, INFO, EPW, NOISE>), grid, block, 0, st, q, a.reset, a.au, env_begin, env_end, a.actions, (T*)a.pos,

@@ -41,9 +41,7 @@ struct WaveParams {
     long long n_envs;
     int A, L, dim_c, n_speak_rows;
     T done_bound;       // > 0: a world is done when an agent leaves [-done_bound, done_bound]^2 (mpe_set_done_bound)
-    // wave_stream_kernel: worlds of an even / an odd XCD (0: workgroup i is world i).  Workgroups go to the eight XCDs
-    // round-robin by index: workgroup i is slot i / 8 of XCD i % 8, and slots beyond the XCD's share end at once.
-    int per_xcd[2];
+    XcdDeal deal;       // wave_stream_kernel: worlds dealt unevenly to even and odd XCDs (phase == nullptr: workgroup i is world i)
 };
 
 template <typename T> __device__ __forceinline__ T spread_round(T v) { return (T)(float)v; }
@@ -532,11 +530,9 @@ __global__ __launch_bounds__(NT, 4) void wave_stream_kernel(const WaveParams<T> 
     const int A = p.A, L = p.L, E = A + L;
     const long long B = p.n_envs;
     long long b = blockIdx.x;
-    if (p.per_xcd[0] > 0) {
-        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        if (slot >= p.per_xcd[x & 1]) return;
-        b = (long long)(x >> 1) * (p.per_xcd[0] + p.per_xcd[1]) + (x & 1) * p.per_xcd[0] + slot;
-        if (b >= B) return;
+    if (p.deal.phase != nullptr) {
+        b = xcd_unit(p.deal, blockIdx.x);
+        if (b < 0) return;
     }
     const DevTable* tb = p.table;
     const int OD = 4 + 2 * L + 2 * (A - 1);
@@ -784,7 +780,7 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
     p.n_envs = B;
     p.A = s.A; p.L = s.L; p.dim_c = s.dim_c; p.n_speak_rows = n_speak_rows;
     p.done_bound = (T)a.done_bound;
-    p.per_xcd[0] = p.per_xcd[1] = 0;
+    p.deal = XcdDeal{nullptr, {0, 0}, B};
     dim3 grid((unsigned)B), block(NT);
     if constexpr (EPI == EPI_SPREAD && MODE == WMODE_STEP && sizeof(T) == 4) {
         // a world's block is A * (A + L + 1) coordinate pairs: 16-byte vectors when that is even and the arrays are aligned
@@ -793,18 +789,18 @@ static hipError_t launch_wave_t(const HostSpec& s, const DevTable* table, long l
 #ifndef MPE_WAVE_NO_STREAM   // (defined in diagnostic builds: every launch on wave_kernel)
         // launches of several steps: one wave steps, the other streams (wave_stream_kernel)
         if (quads && !a.noise.enabled && a.au.step_count == nullptr && a.n_steps > 1) {
-            // A launch that streams large blocks ends with the odd XCDs, which write 15-20 % more slowly than the even ones
-            // while all eight stream (per-XCD timestamps, on every box measured): give an even XCD's CUs
-            // m + d worlds each and an odd XCD's m - d, d / m about an eighth.  Whole worlds per CU on both sides matter
-            // (2 048 worlds of 64 + 64: 8 : 8 per CU 0.698 ms, 8.5 : 7.5 0.689, 9 : 7 0.664, 9.25 : 6.75 0.696; 1 536 worlds
-            // 0.559 -> 0.513 ms at 7 : 5; 4 096 worlds 1.402 -> 1.323 ms at 18 : 14); below six worlds per CU a split costs
-            // more than it gains (1 024 worlds: 0.369 -> 0.382 ms), and small blocks are not bound by their stores.
-            const long long per_cu = (B + 255) / 256;
-            if (per_cu >= 6 && (long long)s.A * (s.A + s.L + 1) * 2 * (long long)sizeof(T) >= 32768) {
-                const int d = per_cu >= 12 ? (int)((per_cu + 4) / 8) : 1;
-                p.per_xcd[0] = 32 * (int)(per_cu + d);
-                p.per_xcd[1] = 32 * (int)(per_cu - d);
-                grid = dim3((unsigned)(8 * p.per_xcd[0]));
+            // A launch that streams large blocks ends with the odd XCDs (XcdDeal, mpe_launch.hpp): the worlds are dealt about
+            // 9 : 7 between even and odd XCDs, in whole worlds per CU on both sides (2 048 worlds of 64 + 64: 8 : 8 per CU
+            // 0.698 ms, 8.5 : 7.5 0.689, 9 : 7 0.664, 9.25 : 6.75 0.696; 1 536 worlds 0.559 -> 0.513 ms at 7 : 5; 4 096 worlds
+            // 1.402 -> 1.323 ms at 18 : 14); below six worlds per CU a split costs more than it gains (1 024 worlds:
+            // 0.369 -> 0.382 ms), and small blocks are not bound by their stores.
+            if ((B + 255) / 256 >= 6 && (long long)s.A * (s.A + s.L + 1) * 2 * (long long)sizeof(T) >= 32768) {
+                p.deal = make_xcd_deal(a.xcd_phase, B, 32);
+                if (p.deal.phase != nullptr) {
+                    grid = dim3((unsigned)(8 * p.deal.share[0]));
+                    const hipError_t e = launch_xcd_phase(a.xcd_phase, st);
+                    if (e != hipSuccess) return e;
+                }
             }
             if (s.any_speed_limit())
                 hipLaunchKernelGGL((wave_stream_kernel<T, true>), grid, block, 0, st, p, a.reset, a.actions, (T*)a.pos, (T*)a.vel, (T*)a.obs, (T*)a.rew,

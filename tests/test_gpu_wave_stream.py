@@ -155,3 +155,26 @@ def test_stream_launch_under_graph_capture():
     torch.cuda.synchronize()
     for key in ("obs0", "obs", "rew", "done"):
         assert torch.equal(out[key], want[key]), key
+
+
+def test_uneven_deal_on_a_second_stream_after_other_work():
+    """The XCD that a launch's workgroup 0 lands on changes with the history of the streams (0 in a fresh process); the
+    deal takes it from a one-workgroup launch on the same stream right before the kernel, and is a bijection for any
+    value of it: a launch on a second stream, after work on the first, still steps every world exactly once."""
+    A = L = 64
+    B, T = 1600, 2
+    stepper, roller = _env(A, L, B), _env(A, L, B)
+    a = _actions(T, B, A, 8)
+    first = stepper.reset(seed=6).clone()
+    want = [tuple(x.clone() for x in stepper.step(a[t])[:3]) for t in range(T)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(3):      # alternate streams so that the launches travel through different hardware queues
+        with torch.cuda.stream(side):
+            out = roller.rollout(a, reset_seed=6, obs0=True)
+        side.synchronize()
+        roller._episode = 0
+        assert torch.equal(out["obs0"][0], first)
+        for t in range(T):
+            assert torch.equal(out["obs"][t], want[t][0]) and torch.equal(out["rew"][t], want[t][1]) and torch.equal(out["done"][t], want[t][2]), t
+        (torch.randn(1 << 20, device="cuda:0") * 2).sum().item()
