@@ -422,6 +422,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                 }
             }
             // ---- World.apply_environment_force: pairs in the reference's (a, b) order ----
+#ifdef MPE_ABLATE_SMALL_PHYS        // diagnostic build: no contact forces
+            if (n_steps == 0x7fffffff)
+#endif
 #pragma unroll
             for (int a = 0; a < E; ++a) {
 #pragma unroll
@@ -442,6 +445,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                 }
             }
             // ---- wall contact for every movable entity, after its entity contacts (core.py:182-188) ----
+#ifdef MPE_ABLATE_SMALL_PHYS        // ... and no wall forces
+            if (n_steps == 0x7fffffff)
+#endif
             if (Cfg::N_WALLS > 0) {
 #pragma unroll
                 for (int i = 0; i < A; ++i) {
@@ -637,6 +643,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_ROLLOUT && FULL && !INFO && !NOIS
                 __syncthreads();
                 int nv = nvalid - pass * TROWS;
                 nv = nv < 0 ? 0 : (nv > TROWS ? TROWS : nv);
+#ifdef MPE_ABLATE_COOP_FLUSH        // diagnostic build: the passes' arithmetic without their stores
+                if (n_steps == 0x7fffffff)
+#endif
                 ObsTile::template flush<FULL, NT>(tile_obs, obs_dst + (long long)(pass * TROWS) * OT, lane, nv);
                 __syncthreads();
                 STAMP_T(33 + pass);
