@@ -178,3 +178,38 @@ def test_uneven_deal_on_a_second_stream_after_other_work():
         for t in range(T):
             assert torch.equal(out["obs"][t], want[t][0]) and torch.equal(out["rew"][t], want[t][1]) and torch.equal(out["done"][t], want[t][2]), t
         (torch.randn(1 << 20, device="cuda:0") * 2).sum().item()
+
+
+_DIGESTS = r"""
+import hashlib, os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "multiagent-particle-envs_amd"))
+import torch, mpe_hip
+def digest(scenario, B, T, **kw):
+    env = mpe_hip.BatchedEnv(scenario, B, dtype=torch.float32, device="cuda:0", **kw)
+    a = torch.randint(0, 5, (T, B, env.n_act), dtype=torch.int32, device="cuda:0", generator=torch.Generator("cuda:0").manual_seed(B))
+    out = env.rollout(a, reset_seed=3, obs0=True)
+    h = hashlib.sha256()
+    for k in ("obs0", "obs", "rew", "done"):
+        h.update(out[k].cpu().numpy().tobytes())
+    h.update(env.pos.cpu().numpy().tobytes())
+    return h.hexdigest()
+print(digest("simple_spread", 1600, 2, n_agents=64, n_landmarks=64))
+print(digest("simple_spread", 8192 * 64 + 64, 2))
+print(digest("consensus", 65536 + 32, 2))
+"""
+
+
+def test_results_do_not_depend_on_the_deal():
+    """MPE_XCD_SPLIT=0 switches the uneven deal over the XCDs off for a process: the three kinds of launch it applies to
+    must produce the same bytes either way (it only decides which workgroup steps which world)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for split in ("1", "0"):
+        env = dict(os.environ, MPE_XCD_SPLIT=split)
+        r = subprocess.run([sys.executable, "-c", _DIGESTS, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([line for line in r.stdout.split() if len(line) == 64])
+    assert len(outs[0]) == 3 and outs[0] == outs[1]
