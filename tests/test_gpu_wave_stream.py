@@ -213,3 +213,16 @@ def test_results_do_not_depend_on_the_deal():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([line for line in r.stdout.split() if len(line) == 64])
     assert len(outs[0]) == 3 and outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("A,L", [(64, 64), (10, 7)])
+def test_episode_launch_without_the_reset_observation(A, L):
+    """The reset state's observation is optional (obs0 = NULL at the C ABI): the steps' outputs are the same."""
+    B, T = 20, 5
+    with_obs0, without = _env(A, L, B, info=True), _env(A, L, B, info=True)
+    a = _actions(T, B, A, 9)
+    o1 = with_obs0.rollout(a, reset_seed=12, obs0=True)
+    o2 = without.rollout(a, reset_seed=12)
+    for key in ("obs", "rew", "done", "info_i", "info_f"):
+        assert torch.equal(o1[key], o2[key]), key
+    _same_state(with_obs0, without)
